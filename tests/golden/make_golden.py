@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by importing the REFERENCE's own
+functions (read-only, from /root/reference) and running them on seeded synthetic
+inputs and on the data artefacts the reference ships (moe_kernels/*.npy, moe_model.pth,
+output/single_kernel/kernelgan_out*/kernel_*.npy).
+
+Run once in the build container (the GPU box never sees /root/reference):
+
+    python tests/golden/make_golden.py
+
+What gets written is DATA only (inputs, expected outputs, re-serialised weights) --
+never reference source text.  Each .npz notes the reference file:line that produced it.
+
+Reference modules import `netCDF4` at top level; it is not installed here, so a stub
+module is registered first.  Only pure-tensor functions are called.
+"""
+import importlib.util
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _import_reference():
+    stub = types.ModuleType("netCDF4")
+    stub.Dataset = object
+    sys.modules["netCDF4"] = stub
+    import matplotlib
+    matplotlib.use("Agg")
+    k = os.path.join(REF, "kernel_from_lr_gan")
+    mods = {}
+    mods["c30"] = _load("ref_c30", os.path.join(k, "C_30apply_kernel_to_landsat.py"))
+    mods["c31"] = _load("ref_c31", os.path.join(k, "C_31apply_muti_kernel_to_landsat.py"))
+    mods["d"] = _load("ref_d", os.path.join(k, "D_build_noise_pool.py"))
+    mods["e"] = _load("ref_e", os.path.join(k, "E_make_train_data.py"))
+    # muti_kernel uses bare `from networks import ...`
+    sys.path.insert(0, os.path.join(k, "muti_kernel"))
+    mods["mnet"] = _load("networks", os.path.join(k, "muti_kernel", "networks.py"))
+    mods["mloss"] = _load("loss", os.path.join(k, "muti_kernel", "loss.py"))
+    mods["gemini"] = _load("ref_gemini", os.path.join(k, "muti_kernel", "train_gemini.py"))
+    sys.path.pop(0)
+    mods["snet"] = _load("ref_single_networks", os.path.join(k, "single_kernel", "networks.py"))
+    return mods
+
+
+def landsat_like(shape, seed):
+    """Synthetic 'Landsat-shaped' radiance tile: rand*80+20, seeded."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g) * 80.0 + 20.0
+
+
+def main():
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    m = _import_reference()
+    quiet = open(os.devnull, "w")
+
+    # ------------------------------------------------------------------ kernels / sigmas (data)
+    moe_k = np.stack([np.load(f"{REF}/moe_kernels/kernel_{i}.npy") for i in range(10)]).astype(np.float32)
+    moe_s = np.stack([np.load(f"{REF}/moe_kernels/sigma_{i}.npy") for i in range(10)]).astype(np.float32)
+    kg_pb = np.load(f"{REF}/output/single_kernel/kernelgan_out/kernel_per_band.npy").astype(np.float32)
+    kg_mg = np.load(f"{REF}/output/single_kernel/kernelgan_out/kernel_merged.npy").astype(np.float32)
+    kg128_pb = np.load(f"{REF}/output/single_kernel/kernelgan_out_128/kernel_per_band.npy").astype(np.float32)
+    np.savez_compressed(
+        os.path.join(OUT, "kernels.npz"),
+        moe_kernels=moe_k, moe_sigmas=moe_s,
+        kgan_per_band=kg_pb, kgan_merged=kg_mg, kgan128_per_band=kg128_pb,
+        note="moe_kernels/kernel_i.npy,sigma_i.npy; output/single_kernel/kernelgan_out{,_128}/kernel_{per_band,merged}.npy",
+    )
+
+    # ------------------------------------------------------------------ V-A  apply_kernel_degradation
+    # C_30apply_kernel_to_landsat.py:68-124 == C_31apply_muti_kernel_to_landsat.py:59-97
+    va = {}
+    zero_band = moe_k[0].copy()
+    zero_band[2] = 0.0                      # a band with sum 0 is left un-normalised (C_30:93-97)
+    unnorm = kg_pb * np.array([2.0, 0.5, 3.0, 1.0, 0.25], np.float32)[:, None, None]
+    cases = [
+        # name,            (C,H,W),        f,  kernel,              seed
+        ("c5_512_f4_moe0", (5, 512, 512), 4, moe_k[0], 0),
+        ("c5_512_f8_moe0", (5, 512, 512), 8, moe_k[0], 0),
+        ("c5_256_f8_kgan", (5, 256, 256), 8, kg_pb, 1),
+        ("c3_256_f4_merged2d", (3, 256, 256), 4, kg_mg, 2),
+        ("c7_260x257_f4_merged2d", (7, 260, 257), 4, kg_mg, 3),
+        ("c5_96_f6_is_f4", (5, 96, 96), 6, moe_k[3], 4),
+        ("c5_64_f1", (5, 64, 64), 1, kg128_pb, 5),
+        ("c5_64_f2", (5, 64, 64), 2, kg128_pb, 6),
+        ("c5_128_f16", (5, 128, 128), 16, moe_k[7], 7),
+        ("c5_70x90_f8_odd", (5, 70, 90), 8, kg_pb, 8),
+        ("c5_64_f4_zero_band", (5, 64, 64), 4, zero_band, 9),
+        ("c5_64_f4_unnormalised", (5, 64, 64), 4, unnorm, 10),
+        ("c5_16_f4_tiny", (5, 16, 16), 4, moe_k[1], 11),
+    ]
+    stdout = sys.stdout
+    for name, shape, f, kern, seed in cases:
+        img = landsat_like(shape, seed)
+        k = torch.from_numpy(kern.copy())
+        o30 = m["c30"].apply_kernel_degradation(img, k, f)
+        o31 = m["c31"].apply_kernel_degradation(img, k, f)
+        assert torch.equal(o30, o31), name
+        va[name + "__out"] = o30.numpy()
+        va[name + "__kernel"] = kern
+        va[name + "__meta"] = np.array([shape[0], shape[1], shape[2], f, seed], np.int64)
+        # inputs are regenerated from the seed by the tests; keep a checksum to prove identity
+        va[name + "__in_sum"] = np.array([img.double().sum().item(), img[0, 0, :8].double().sum().item()])
+    # NaN propagation case (inputs stored: small)
+    img = landsat_like((5, 64, 64), 12)
+    img[1, 30, 41] = float("nan")
+    o = m["c30"].apply_kernel_degradation(img, torch.from_numpy(moe_k[0].copy()), 4)
+    va["nan_case__in"] = img.numpy()
+    va["nan_case__out"] = o.numpy()
+    va["nan_case__kernel"] = moe_k[0]
+    va["nan_case__meta"] = np.array([5, 64, 64, 4, 12], np.int64)
+    va["note"] = np.array("C_30apply_kernel_to_landsat.py:68-124 (bit-identical to C_31:59-97); inputs = rand(seed)*80+20")
+    np.savez_compressed(os.path.join(OUT, "va_cases.npz"), **va)
+
+    # load_kernel semantics (C_31:22-37): 4-D -> mean over batch, 2-D -> [1,k,k]
+    sys.stdout = quiet
+    tmp = os.path.join(OUT, "_tmp_kernel.npy")
+    batch_k = np.stack([moe_k[0], moe_k[4], moe_k[9]]).astype(np.float64)   # float64 on disk -> cast to f32
+    np.save(tmp, batch_k)
+    lk4 = m["c31"].load_kernel(tmp).numpy()
+    np.save(tmp, kg_mg)
+    lk2_c31 = m["c31"].load_kernel(tmp).numpy()
+    lk2_c30 = m["c30"].load_kernel(tmp).numpy()
+    os.remove(tmp)
+    sys.stdout = stdout
+    np.savez_compressed(os.path.join(OUT, "load_kernel.npz"), batch_in=batch_k, batch_out=lk4,
+                        k2d_in=kg_mg, k2d_out_c31=lk2_c31, k2d_out_c30=lk2_c30,
+                        note="C_31:22-37 / C_30:18-33")
+
+    # ------------------------------------------------------------------ V-B  deterministic part + full forward
+    # train_gemini.py:124-134 (grouped conv, zero pad 6, ::4)
+    vb = {}
+    import torch.nn.functional as F
+    for name, (B, C, H, W), seed in [("b4_256", (4, 5, 256, 256), 20), ("b3_250x253", (3, 5, 250, 253), 21),
+                                     ("b2_64", (2, 5, 64, 64), 22)]:
+        x = landsat_like((B, C, H, W), seed)
+        kid = np.array([(3 * i + 1) % 10 for i in range(B)], np.int32)
+        bk = torch.from_numpy(moe_k[kid])                          # [B,C,13,13]
+        out = F.conv2d(x.view(1, B * C, H, W), bk.view(B * C, 1, 13, 13), padding=6, groups=B * C)
+        out = out.view(B, C, H, W)[:, :, ::4, ::4].contiguous()
+        vb[name + "__out"] = out.numpy()
+        vb[name + "__kid"] = kid
+        vb[name + "__meta"] = np.array([B, C, H, W, seed], np.int64)
+        vb[name + "__in_sum"] = np.array([x.double().sum().item()])
+    # peaked kernels (kgan) so that border attenuation / asymmetry is exercised
+    x = landsat_like((2, 5, 96, 96), 23)
+    bk = torch.from_numpy(np.stack([kg_pb, kg128_pb]))
+    out = F.conv2d(x.view(1, 10, 96, 96), bk.view(10, 1, 13, 13), padding=6, groups=10).view(2, 5, 96, 96)[:, :, ::4, ::4]
+    vb["kgan_b2_96__out"] = out.contiguous().numpy()
+    vb["kgan_b2_96__kernels"] = bk.numpy()
+    vb["kgan_b2_96__meta"] = np.array([2, 5, 96, 96, 23], np.int64)
+
+    model = m["gemini"].ContentAdaptiveDegradation(n_kernels=10, n_channels=5, kernel_size=13)
+    sd = torch.load(f"{REF}/moe_kernels/moe_model.pth", weights_only=True, map_location="cpu")
+    model.load_state_dict(sd)
+    model.eval()
+    x = landsat_like((4, 5, 256, 256), 20)
+    with torch.no_grad():
+        logits = model.selector(x)
+        vk = model.get_effective_kernels()
+        vs = model.get_effective_sigmas()
+        torch.manual_seed(123)
+        out, weights, valid_k = model(x, temp=1.0, hard=True)
+        # soft mixing path: weights given, deterministic part only
+        torch.manual_seed(7)
+        w_soft = F.gumbel_softmax(logits, tau=1.0, hard=False, dim=1)
+        bk = torch.einsum("bk,kchw->bchw", w_soft, vk)
+        bs = torch.einsum("bk,kc->bc", w_soft, vs)
+        soft_clean = F.conv2d(x.view(1, 20, 256, 256), bk.reshape(20, 1, 13, 13), padding=6, groups=20)
+        soft_clean = soft_clean.view(4, 5, 256, 256)[:, :, ::4, ::4].contiguous()
+    vb["fwd__logits"] = logits.numpy()
+    vb["fwd__valid_kernels"] = vk.numpy()
+    vb["fwd__valid_sigmas"] = vs.numpy()
+    vb["fwd__hard_weights"] = weights.numpy()
+    vb["fwd__hard_out"] = out.numpy()           # includes torch-CPU randn noise: statistical use only
+    vb["fwd__soft_weights"] = w_soft.numpy()
+    vb["fwd__soft_kernels"] = bk.numpy()
+    vb["fwd__soft_sigmas"] = bs.numpy()
+    vb["fwd__soft_clean"] = soft_clean.numpy()
+    vb["note"] = np.array("train_gemini.py:88-140; x=rand(seed 20)*80+20 [4,5,256,256]; moe_model.pth eval mode")
+    np.savez_compressed(os.path.join(OUT, "vb_cases.npz"), **vb)
+
+    # selector weights as data (state_dict tensors re-serialised) -> lets the GPU box rebuild the model
+    np.savez_compressed(os.path.join(OUT, "moe_model_state.npz"),
+                        **{k: v.numpy() for k, v in sd.items()})
+
+    # ------------------------------------------------------------------ V-C  add_noise / random_crop index streams
+    # E_make_train_data.py:65-74 with np.random.seed(42) (E:190); D_build_noise_pool.py:41-53 with random.seed(42) (D:65)
+    pool = np.arange(1000 * 5 * 4 * 4, dtype=np.float32).reshape(1000, 5, 4, 4)
+    blurred = np.zeros((5, 4, 4), np.float32)
+    np.random.seed(42)
+    idxs = []
+    for _ in range(32):
+        o = m["e"].add_noise(blurred, pool)
+        idxs.append(int(o[0, 0, 0]) // (5 * 4 * 4))
+    data = np.arange(5 * 256 * 256, dtype=np.float32).reshape(5, 256, 256)
+    random.seed(42)
+    crops = m["d"].random_crop(data, 32, 16)
+    offs = [(int(c[0, 0, 0]) // 256, int(c[0, 0, 0]) % 256) for c in crops]
+    random.seed(42)
+    crops_b = m["d"].random_crop(data[:, :40, :33], 32, 8)   # tight bounds: inclusive upper limit matters
+    offs_b = [(int(c[0, 0, 0]) // 256, int(c[0, 0, 0]) % 256) for c in crops_b]
+    np.savez_compressed(os.path.join(OUT, "rng_streams.npz"),
+                        add_noise_idx_seed42_N1000=np.array(idxs, np.int64),
+                        random_crop_offs_seed42_256=np.array(offs, np.int64),
+                        random_crop_offs_seed42_40x33=np.array(offs_b, np.int64),
+                        note="E_make_train_data.py:65-74,190; D_build_noise_pool.py:41-53,65")
+
+    # ------------------------------------------------------------------ KernelGAN: extract_effective_kernels + forward
+    # muti_kernel/networks.py:101-202 ; single_kernel/networks.py:83-157
+    kg = {}
+    torch.manual_seed(0)
+    dm = m["mnet"].DegradationModel(in_ch=5, mid_ch=32, ks=(7, 5, 3, 1, 1, 1), scale_gain=0.1,
+                                    noise_init=0.3, noise_max=1.2)
+    # the default init (randn*0.01) composes to ~1e-12 kernels -> clamp/normalise degenerate; scale up so the
+    # composed kernel has O(1) mass and mixed signs (exercises clamp>=0 and the sum normalisation)
+    with torch.no_grad():
+        for band in dm.generator.weight_bands:
+            for li, w in enumerate(band):
+                w.mul_(100.0 / (w.shape[1] ** 0.5) / w.shape[-1])
+                if li == 0:
+                    w.add_(0.05)
+    dm.eval()
+    x = landsat_like((2, 5, 64, 64), 30) / 100.0
+    with torch.no_grad():
+        k_b = dm.generator.extract_effective_kernels(x, reduce_batch=False)       # [2,5,13,13]
+        k_r = dm.generator.extract_effective_kernels(x, reduce_batch=True)        # [5,13,13]
+        k_none = dm.generator.extract_effective_kernels(None)                     # [5,13,13]
+        scales = dm.generator.condition_encoder(x)
+        fwd = dm.generator(x)                                                     # [2,5,8,8]
+    for k_, v in dm.state_dict().items():
+        kg["muti_sd__" + k_] = v.numpy()
+    kg["muti__x"] = x.numpy()
+    kg["muti__kernels_batch"] = k_b.numpy()
+    kg["muti__kernels_reduced"] = k_r.numpy()
+    kg["muti__kernels_noinput"] = k_none.numpy()
+    kg["muti__forward"] = fwd.numpy()
+    kg["muti__scales"] = np.stack([np.concatenate([s.numpy() for s in band], axis=1) for band in scales], axis=1)  # [B,5,161]
+    # NoiseEstimator sigma clamp (networks.py:221-224)
+    with torch.no_grad():
+        _, sig = dm.noise_estimator(torch.zeros(1, 5, 4, 4))
+    kg["muti__noise_sigma"] = sig.numpy()
+
+    sg = m["snet"].MultiBandLinearGenerator(in_ch=5, mid_ch=32)
+    with torch.no_grad():
+        kg["single_default__kernels"] = sg.extract_effective_kernels().numpy()
+        xs = landsat_like((2, 5, 64, 64), 31)
+        kg["single_default__forward"] = sg(xs).numpy()
+        torch.manual_seed(1)
+        for p in sg.parameters():
+            p.add_(torch.randn_like(p) * 0.02)
+        kg["single_perturbed__kernels"] = sg.extract_effective_kernels().numpy()
+        kg["single_perturbed__forward"] = sg(xs).numpy()
+    for k_, v in sg.state_dict().items():
+        kg["single_perturbed_sd__" + k_] = v.numpy()
+    kg["single__x_meta"] = np.array([2, 5, 64, 64, 31], np.int64)
+    kg["note"] = np.array("muti_kernel/networks.py:101-202 (DegradationModel seed 0, weights rescaled, see make_golden.py); "
+                          "single_kernel/networks.py:83-157")
+    np.savez_compressed(os.path.join(OUT, "kernelgan.npz"), **kg)
+
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f"{f:28s} {os.path.getsize(os.path.join(OUT, f)) / 1024:9.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()
