@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- hot-path throughput on MI355X (contract: see the task statement / DESIGN.md "Measurement").
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic Landsat-shaped patches that is already
+resident in HBM.  Patches are independent, so ranks shard them with no data-path collective (weak scaling:
+fixed per-GPU batch); the only collectives are the barrier around the timed region and a MAX of the
+per-rank wall time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import kmsr_amd  # noqa: E402
+from kmsr_amd import _lib as L  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+F32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 MFMA / vector peak
+
+
+def synth_hr(n, c, h, w, device, seed):
+    """Synthetic 'Landsat-shaped' TOA radiance tiles: U(20,100), fp32, NaN-free."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    return torch.rand(n, c, h, w, device=device, generator=g) * 80.0 + 20.0
+
+
+def moe_bank(device):
+    """The reference's shipped 10-kernel / sigma bank (moe_kernels/*.npy), carried as fixture data."""
+    k = np.load(os.path.join(ROOT, "tests", "golden", "kernels.npz"))
+    return torch.from_numpy(k["moe_kernels"]).to(device), torch.from_numpy(k["moe_sigmas"]).to(device)
+
+
+class DegradeWorkload:
+    """north-star unit of the degradation path: V-B on-the-fly degradation of
+    HR [B,5,1024,1024] -> LR [B,5,256,256]: per-sample kernel from the 10-kernel bank, stride 4, zero pad,
+    Gaussian sigma noise from the in-kernel Philox stream (train_gemini.py:117-138)."""
+    name = "degrade_vb_x4_hr1024_c5_b32"
+
+    def __init__(self, device, rank, batch=32, C=5, H=1024, W=1024):
+        self.B, self.C, self.H, self.W = batch, C, H, W
+        self.hr = synth_hr(batch, C, H, W, device, seed=1000 + rank)
+        self.bank, self.sigma = moe_bank(device)
+        g = torch.Generator().manual_seed(rank)
+        self.kid = torch.randint(0, 10, (batch,), generator=g, dtype=torch.int32).to(device)
+        self.lr = torch.empty(batch, C, H // 4, W // 4, device=device)
+        self.ws = kmsr_amd.workspace_for(self.hr.shape, self.bank.shape, 4, "stride", device)
+        self.step_no = 0
+        self.taps_ready = False
+        # algorithmic bytes per patch: HR read once + LR written once + kernel taps
+        self.bytes_per_patch = 4 * C * H * W + 4 * C * (H // 4) * (W // 4) + 4 * C * 13 * 13
+        self.patches_per_step = batch
+
+    def step(self):
+        kmsr_amd.degrade_batch(self.hr, self.bank, 4, down="stride", pad="zero", normalize=False,
+                               kernel_idx=self.kid, sigma=self.sigma, noise="gaussian", seed=42, offset=self.step_no,
+                               out=self.lr, workspace=self.ws, taps_ready=self.taps_ready, flags=L.FLAG_FORCE_FAST)
+        self.taps_ready = True      # the bank is fixed: the tap table is built once (first warm-up step)
+        self.step_no += 1
+
+    def roofline(self, kernel_ms):
+        achieved = self.bytes_per_patch * self.patches_per_step / (kernel_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "degrade_rowstream_kernel<4,13,13,6,6,2>", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": self.bytes_per_patch * self.patches_per_step,
+                "kernel_ms": round(kernel_ms, 4)}
+
+    def cpu_baseline(self, budget_s=12.0):
+        """The oracle (CPU restatement of train_gemini.py:124-138) on a bounded sample of the same workload."""
+        import oracle
+        cores = oracle.set_threads(os.cpu_count() or 1)
+        hr = self.hr[:2].cpu().numpy()
+        kern = self.bank[self.kid[:2].long()].cpu().numpy()
+        sig = self.sigma[self.kid[:2].long()].cpu().numpy().reshape(-1)
+
+        def one():
+            clean = oracle.vb_blur_stride(hr, kern, 4)
+            oracle.add_gaussian_noise(clean, sig, seed=42, offset=0)
+        one()
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            one()
+            n += 2
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 64:
+                break
+        return {"value": round(n / el, 2), "unit": "LR patches/s", "cores": cores, "kind": "port",
+                "sample": f"{n} patches of HR 5x1024x1024 -> LR 256^2 (oracle vb_blur_stride + Philox noise, "
+                          f"{el:.1f} s, OpenMP over {cores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", local if world > 1 else 0)
+    L.require_gpu()
+
+    wl = DegradeWorkload(device, rank)
+    for _ in range(max(args.warmup, 1)):
+        wl.step()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()                       # on torch's current stream == the stream the kernels are launched on
+    for _ in range(args.steps):
+        wl.step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps      # one dominant kernel per step, back to back on one stream
+
+    if dist:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_patches = wl.patches_per_step * args.steps * world
+        out = {
+            "metric": "LR patches/sec (degrade+SR fwd) x4 256^2",
+            "value": round(total_patches / elapsed, 2),
+            "unit": "LR patches/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl.name, "hr": [wl.B, wl.C, wl.H, wl.W], "factor": 4,
+                       "stage": "degrade only (SR forward joins the step once its HIP kernels land)",
+                       "sharding": f"independent patches, {wl.B}/GPU, no data-path collective"},
+            "roofline": wl.roofline(kernel_ms),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = wl.cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+/*
+ * kmsr.h -- C ABI of libkmsr_hip.so, the MI355X (gfx950) implementation of the
+ * degradation-synthesis + SR-CNN hot path of Zhiyyeah/Kernel-Modeling-Super-Resolution.
+ *
+ * The reference has no FFI: its boundary is a set of Python callables operating on torch / numpy
+ * arrays.  Each entry point below is what a binding for one of those callables would call; the
+ * reference interface it replaces is cited as file:line (paths relative to the upstream repo).
+ * Python-side stubs a maintainer would add are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - All tensor pointers are DEVICE pointers (HBM) unless a parameter says "host".
+ *   - The caller owns every buffer, including the workspace (size it with the *_workspace_bytes query).
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  Calls are asynchronous with
+ *     respect to the host and re-entrant; the library keeps no global mutable state.
+ *   - Return value: KMSR_OK (0) or a negative KMSR_E_* code; kmsr_last_error() returns a
+ *     thread-local message for the last failing call on this thread.  Nothing throws or aborts.
+ */
+#ifndef KMSR_H
+#define KMSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMSR_VERSION 100 /* 0.1.0 */
+
+#define KMSR_OK 0
+#define KMSR_E_BADARG (-1)      /* null pointer / bad enum / misaligned         -> Python ValueError   */
+#define KMSR_E_SHAPE (-2)       /* band / size mismatch (C_30:88 assert)         -> AssertionError      */
+#define KMSR_E_HIP (-3)         /* a HIP runtime call failed                    -> RuntimeError        */
+#define KMSR_E_RCCL (-4)        /* reserved for the collective layer                                   */
+#define KMSR_E_NOMEM (-5)       /* workspace too small                          -> MemoryError         */
+#define KMSR_E_UNSUPPORTED (-6) /* configuration outside the implemented range  -> NotImplementedError */
+
+int kmsr_version(void);
+const char* kmsr_last_error(void);
+/* number of visible HIP devices, or a negative error code */
+int kmsr_device_count(void);
+
+/* ============================================================================================
+ * Fused degradation: blur (depthwise cross-correlation) + downsample + noise, one launch per batch.
+ *
+ * Replaces
+ *   apply_kernel_degradation(img, kernel, downscale_factor)   C_30apply_kernel_to_landsat.py:68-124
+ *                                                             C_31apply_muti_kernel_to_landsat.py:59-97
+ *       -> down=KMSR_DOWN_AVGPOOL, pad=KMSR_PAD_REPLICATE, normalize=1, noise=KMSR_NOISE_NONE
+ *   ContentAdaptiveDegradation.forward steps 3-5              muti_kernel/train_gemini.py:117-138
+ *       -> down=KMSR_DOWN_STRIDE,  pad=KMSR_PAD_ZERO,      normalize=0, noise=KMSR_NOISE_GAUSSIAN
+ *   add_noise(blurred, noise_pool)                            E_make_train_data.py:65-74
+ *       -> noise=KMSR_NOISE_POOL (fused into the epilogue of either of the above)
+ *   NoiseEstimator.forward                                    muti_kernel/networks.py:221-224
+ *       -> noise=KMSR_NOISE_GAUSSIAN with sigma already clamped by the caller
+ *
+ * Semantics (SURVEY.md section 8 a'):  p_h = kh/2, p_w = kw/2,
+ *   AVGPOOL: s = floor(log2(factor)), F = 2^s, h = H>>s, w = W>>s,
+ *            out[n,c,i,j] = mean_{dy,dx<F} blur[n,c,F*i+dy,F*j+dx]       (the cascade of s 2x2 avg-pools)
+ *   STRIDE : F = factor, h = ceil(H/F), w = ceil(W/F), out[n,c,i,j] = blur[n,c,F*i,F*j]
+ *   blur[n,c,y,x] = sum_{u,v} K[row(n),c,u,v] * hr[n,c,pad(y+u-p_h),pad(x+v-p_w)]
+ *   REPLICATE: pad() clamps to the image; ZERO: out-of-image taps contribute 0.
+ *   normalize=1: K[r,c] /= sum(K[r,c]) when that sum is > 0 (C_30:93-97).
+ *   row(n) = kernel_idx[n] if kernel_idx else (n_kernels == 1 ? 0 : n).
+ *   GAUSSIAN: out += sigma[row(n),c] * eps(n*C+c, i, j) with the counter-based Philox stream
+ *             documented in DESIGN.md ("noise stream"); (seed, offset) select the stream.
+ *   POOL    : out += noise[noise_idx ? noise_idx[n] : n, c, i, j]   (noise is [pool_size,C,h,w])
+ * ========================================================================================== */
+enum { KMSR_DOWN_AVGPOOL = 0, KMSR_DOWN_STRIDE = 1 };
+enum { KMSR_PAD_REPLICATE = 0, KMSR_PAD_ZERO = 1 };
+enum { KMSR_NOISE_NONE = 0, KMSR_NOISE_GAUSSIAN = 1, KMSR_NOISE_POOL = 2 };
+
+#define KMSR_FLAG_FORCE_GENERIC 1u /* always use the generic (one thread per output) kernel        */
+#define KMSR_FLAG_FORCE_FAST 2u    /* fail with KMSR_E_UNSUPPORTED instead of falling back to generic */
+#define KMSR_FLAG_TAPS_READY 4u    /* workspace already holds the tap table of an earlier call with the
+                                      same kernels / kh / kw / factor / down_mode / normalize: skip its rebuild */
+
+typedef struct kmsr_degrade_desc {
+    int32_t N, C, H, W;      /* HR batch [N,C,H,W], fp32, unit stride along W                      */
+    int64_t hr_stride_n;     /* element strides of hr                                               */
+    int64_t hr_stride_c;
+    int64_t hr_stride_h;
+    int32_t n_kernels;       /* kernels is [n_kernels,C,kh,kw] contiguous                            */
+    int32_t kh, kw;          /* odd, <= 31                                                           */
+    int32_t factor;          /* the caller's downscale_factor                                        */
+    int32_t down_mode;       /* KMSR_DOWN_*                                                          */
+    int32_t pad_mode;        /* KMSR_PAD_*                                                           */
+    int32_t normalize;       /* 0/1                                                                  */
+    int32_t noise_mode;      /* KMSR_NOISE_*                                                         */
+    int32_t pool_size;       /* KMSR_NOISE_POOL: leading dim of `noise`                              */
+    uint32_t flags;          /* KMSR_FLAG_*                                                          */
+    uint64_t seed;           /* KMSR_NOISE_GAUSSIAN                                                  */
+    uint32_t offset;         /* KMSR_NOISE_GAUSSIAN: stream offset (e.g. training step)             */
+    int32_t rows_per_chunk;  /* tuning: LR rows per wave in the row-streaming kernel, 0 = auto      */
+} kmsr_degrade_desc;
+
+/* LR size for a descriptor (pure host arithmetic). */
+int kmsr_degrade_out_shape(const kmsr_degrade_desc* d, int32_t* h, int32_t* w);
+/* Bytes of device workspace kmsr_degrade_f32 needs (effective tap tables). */
+size_t kmsr_degrade_workspace_bytes(const kmsr_degrade_desc* d);
+/* 1 if this descriptor is served by the row-streaming fast kernel, 0 if by the generic kernel. */
+int kmsr_degrade_uses_fast_path(const kmsr_degrade_desc* d, const void* hr);
+
+int kmsr_degrade_f32(const kmsr_degrade_desc* d,
+                     const float* hr,            /* [N,C,H,W] (strided)                              */
+                     const float* kernels,       /* [n_kernels,C,kh,kw]                              */
+                     const int32_t* kernel_idx,  /* [N] or NULL                                      */
+                     const float* sigma,         /* [n_kernels,C]      (GAUSSIAN) else NULL          */
+                     const float* noise,         /* [pool_size,C,h,w]  (POOL)     else NULL          */
+                     const int64_t* noise_idx,   /* [N] or NULL        (POOL)                        */
+                     float* lr,                  /* [N,C,h,w] contiguous                             */
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* eps stream only: out[p,i,j] = eps(p,i,j)  (tests; p < planes) */
+int kmsr_gaussian_eps_f32(float* out, int32_t planes, int32_t h, int32_t w, uint64_t seed, uint32_t offset,
+                          void* stream);
+
+/* ============================================================================================
+ * Noise-pool construction.  D_build_noise_pool.py:41-53,88: out[t] = (geo - den)[:, top:top+cs, left:left+cs]
+ *   geo, den [C,H,W]; offs DEVICE int32 array [n][2] = (top,left) drawn by the caller with Python's `random`
+ *   (D:49-50, inclusive bounds) so the integer stream stays bit-identical to the reference.
+ * ========================================================================================== */
+int kmsr_noise_crops_f32(const float* geo, const float* den, int32_t C, int32_t H, int32_t W,
+                         const int32_t* offs, int32_t n, int32_t crop, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMSR_H */

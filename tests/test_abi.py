@@ -1,0 +1,137 @@
+"""CPU-side checks of the drop-in boundary: libkmsr_hip.so loads and exports every symbol that
+include/kmsr.h declares; host-only entry points behave; the product package refuses to run without
+a GPU instead of silently falling back."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import kmsr_amd
+from kmsr_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "kmsr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(kmsr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported_and_bound():
+    lib = L.load()
+    names = _declared_symbols()
+    assert "kmsr_degrade_f32" in names and "kmsr_version" in names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/kmsr.h but not exported by libkmsr_hip.so"
+        assert n in L.SYMBOLS, f"{n} has no ctypes prototype in _lib.SYMBOLS"
+    assert sorted(L.SYMBOLS) == names, "ctypes table and header disagree"
+    assert lib.kmsr_version() == 100
+
+
+def test_struct_layout_matches_header():
+    # kmsr_degrade_desc: 4*i32, 3*i64, 9*i32 + u32, u64, u32, i32  (natural alignment)
+    assert C.sizeof(L.DegradeDesc) == 16 + 24 + 40 + 8 + 8
+    assert L.DegradeDesc.hr_stride_n.offset == 16 and L.DegradeDesc.seed.offset == 80
+
+
+def _desc(**kw):
+    d = L.DegradeDesc()
+    d.N, d.C, d.H, d.W = 1, 5, 512, 512
+    d.hr_stride_n, d.hr_stride_c, d.hr_stride_h = 5 * 512 * 512, 512 * 512, 512
+    d.n_kernels, d.kh, d.kw, d.factor = 1, 13, 13, 8
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+@pytest.mark.parametrize("H,W,f,mode,want", [
+    (512, 512, 8, L.DOWN_AVGPOOL, (64, 64)), (512, 512, 4, L.DOWN_AVGPOOL, (128, 128)),
+    (96, 96, 6, L.DOWN_AVGPOOL, (24, 24)),            # int(log2(6)) = 2 -> x4   (C_30:120)
+    (70, 90, 8, L.DOWN_AVGPOOL, (8, 11)),             # floor at every pooling level
+    (64, 64, 1, L.DOWN_AVGPOOL, (64, 64)), (7, 7, 8, L.DOWN_AVGPOOL, (0, 0)),
+    (250, 253, 4, L.DOWN_STRIDE, (63, 64)),           # [::4] -> ceil     (train_gemini.py:134)
+    (256, 256, 3, L.DOWN_STRIDE, (86, 86)),
+])
+def test_out_shape_host_arithmetic(H, W, f, mode, want):
+    lib = L.load()
+    h, w = C.c_int32(), C.c_int32()
+    assert lib.kmsr_degrade_out_shape(_desc(H=H, W=W, factor=f, down_mode=mode), h, w) == 0
+    assert (h.value, w.value) == want
+    # the reference's own formula
+    if mode == L.DOWN_AVGPOOL:
+        hh, ww = H, W
+        for _ in range(int(np.log2(f))):
+            hh, ww = hh // 2, ww // 2
+        assert (hh, ww) == want
+
+
+def test_error_codes_and_messages_without_gpu():
+    lib = L.load()
+    h, w = C.c_int32(), C.c_int32()
+    assert lib.kmsr_degrade_out_shape(_desc(kh=12), h, w) == L.KMSR_E_UNSUPPORTED
+    assert b"kernel size" in lib.kmsr_last_error()
+    assert lib.kmsr_degrade_out_shape(_desc(factor=0), h, w) == L.KMSR_E_BADARG
+    assert lib.kmsr_degrade_out_shape(_desc(down_mode=7), h, w) == L.KMSR_E_BADARG
+    assert lib.kmsr_degrade_out_shape(None, h, w) == L.KMSR_E_BADARG
+    with pytest.raises(ValueError):
+        L.check(L.KMSR_E_BADARG)
+    with pytest.raises(AssertionError):
+        L.check(L.KMSR_E_SHAPE)
+    with pytest.raises(MemoryError):
+        L.check(L.KMSR_E_NOMEM)
+    # null tensors are rejected before any launch
+    d = _desc()
+    assert lib.kmsr_degrade_f32(d, None, None, None, None, None, None, None, None, 0, None) == L.KMSR_E_BADARG
+    assert lib.kmsr_degrade_workspace_bytes(_desc(factor=4)) == 5 * 16 * 16 * 4
+    assert lib.kmsr_degrade_workspace_bytes(_desc(factor=4, down_mode=L.DOWN_STRIDE)) == 5 * 13 * 16 * 4
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(L.KmsrError):
+        kmsr_amd.apply_kernel_degradation(torch.zeros(5, 64, 64), torch.ones(5, 13, 13), 8)
+    with pytest.raises(L.KmsrError):
+        kmsr_amd.add_noise(np.zeros((5, 32, 32), np.float32), np.zeros((4, 5, 32, 32), np.float32))
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "kernel-modeling-super-resolution_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), f"{f} imports the oracle"
+                assert "libkmsr_oracle" not in txt, f"{f} references the oracle library"
+
+
+def test_load_kernel_semantics(tmp_path):
+    """C_31:22-37 against the fixture produced by the reference's own load_kernel."""
+    from conftest import golden
+    lk = golden("load_kernel.npz")
+    p = str(tmp_path / "k.npy")
+    np.save(p, lk["batch_in"])
+    got = kmsr_amd.load_kernel(p, verbose=False)
+    assert got.dtype.is_floating_point and tuple(got.shape) == (5, 13, 13)
+    np.testing.assert_allclose(got.numpy(), lk["batch_out"], rtol=1e-6)
+    np.save(p, lk["k2d_in"])
+    assert np.array_equal(kmsr_amd.load_kernel(p, verbose=False).numpy(), lk["k2d_out_c31"])
+
+
+def test_random_crop_matches_reference_stream():
+    """D_build_noise_pool.py:41-53"""
+    import random
+    from conftest import golden
+    rng = golden("rng_streams.npz")
+    data = np.arange(5 * 256 * 256, dtype=np.float32).reshape(5, 256, 256)
+    random.seed(42)
+    crops = kmsr_amd.random_crop(data, 32, 16)
+    offs = [(int(c[0, 0, 0]) // 256, int(c[0, 0, 0]) % 256) for c in crops]
+    assert offs == [tuple(o) for o in rng["random_crop_offs_seed42_256"]]
+    assert all(c.shape == (5, 32, 32) for c in crops)
+    with pytest.raises(ValueError):
+        kmsr_amd.random_crop(data[:, :16], 32, 1)
