@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkmsr_hip.so")
+LIB_PATH = os.environ.get("KMSR_LIB_OVERRIDE") or os.path.join(_HERE, "libkmsr_hip.so")   # override: diagnostic builds only
 
 KMSR_OK = 0
 KMSR_E_BADARG, KMSR_E_SHAPE, KMSR_E_HIP, KMSR_E_RCCL, KMSR_E_NOMEM, KMSR_E_UNSUPPORTED = -1, -2, -3, -4, -5, -6

@@ -17,6 +17,15 @@
 //     arrive through the scalar cache (wave-uniform), no block-level barriers exist.
 //   - degrade_generic_kernel: one thread per output, any F / kernel size / alignment.
 #include "kmsr_common.h"
+#ifndef KMSR_ABLATE
+#define KMSR_ABLATE 0
+#endif
+#ifndef KMSR_DMA_AUX
+#define KMSR_DMA_AUX 0  // cache policy of the HR row stream (2 = nt)
+#endif
+
+#include <algorithm>
+#include <cstdlib>
 
 namespace kmsr {
 
@@ -24,6 +33,7 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
+constexpr int kRing = 3;  // LDS row slots per wave (2 rows in flight; measured best of {3,4,6}, profiles/r01)
 
 struct DegradeParams {
     const float* hr;
@@ -135,7 +145,10 @@ __global__ void __launch_bounds__(256) degrade_generic_kernel(DegradeParams p) {
         const float* tp = p.taps + (size_t)(krow * p.C + c) * p.TY * p.TXP;
         const float* img = p.hr + n * p.sN + c * p.sC;
         float acc = 0.f;
-        for (int a = 0; a < p.TY; ++a) {
+        // odd row chunks accumulate tap rows bottom-up (see degrade_rowstream_kernel): keeps the two kernels bit-identical
+        const bool up = ((i / p.rows_per_chunk) & 1) != 0;
+        for (int al = 0; al < p.TY; ++al) {
+            const int a = up ? p.TY - 1 - al : al;
             int y = p.F * i + a - p.ph;
             if (p.pad_zero) {
                 if (y < 0 || y >= p.H) continue;
@@ -196,7 +209,35 @@ template <> struct VecT<4> { using type = f32x4; };
 template <> struct VecT<2> { using type = f32x2; };
 template <> struct VecT<1> { using type = float; };
 
-template <int F, int TY, int TX, int PH, int PW, int NX>
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// s_waitcnt needs an immediate; n is wave-uniform.  Anything above the table waits for more than asked (safe).
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    }
+}
+
+// Row-streaming kernel.  R = LDS ring slots per wave: R-1 HR rows are in flight (LDS-DMA, no staging VGPRs)
+// while one is being folded into the accumulators.
+template <int F, int TY, int TX, int PH, int PW, int NX, int R>
 __global__ void __launch_bounds__(kWave* kWavesPerBlock)
     degrade_rowstream_kernel(const float* __restrict__ hr, const float* __restrict__ taps_all,
                              const float* __restrict__ sigma, const float* __restrict__ noise,
@@ -204,7 +245,7 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
     using Cfg = RowCfg<F, TY, TX, PH, PW, NX>;
     constexpr int TYB = Cfg::TYB, G = Cfg::G, NWG = Cfg::NWG, OFF = Cfg::OFF, HL = Cfg::HL;
     constexpr int ROWF = Cfg::ROWF, NV = Cfg::NV, NLD = Cfg::NLD, SW = Cfg::SW, TXP = Cfg::TXP;
-    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][ROWF];
+    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][R][ROWF];   // the ONLY LDS object (guide 4a)
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -229,8 +270,32 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
     const int i1 = min(i0 + p.rows_per_chunk, p.h);
     const int xs0 = strip * SW;
     const int col0 = F * xs0 - HL;  // HR column of LDS float 0 (multiple of 4)
-    float* __restrict__ row = lds[wid];
+    float* ring = &lds[wid][0][0];
     const bool pad_zero = p.pad_zero != 0;
+
+    // ---- per-lane staging map.  Float4 q of a row segment covers HR columns col0+4q .. +3; W % 4 == 0 and
+    //      col0 % 4 == 0, so it is either entirely inside the image (fetched by LDS-DMA) or entirely outside
+    //      (zero padding: zero-filled once; replicate padding: rewritten per row from the edge pixel).
+    bool inside[NLD], outside[NLD], live[NLD];
+    int nld_live = 0;
+    bool any_outside = false;
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) {
+        const int q = lane + kWave * t;
+        const int c0 = col0 + 4 * q;
+        inside[t] = q < NV && c0 >= 0 && c0 + 3 < W;
+        outside[t] = q < NV && !inside[t];
+        live[t] = __ballot(inside[t]) != 0ull;   // wave-uniform: is the t-th DMA instruction issued at all
+        nld_live += live[t] ? 1 : 0;
+        any_outside = any_outside || (__ballot(outside[t]) != 0ull);
+    }
+    if (pad_zero && any_outside) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int t = 0; t < NLD; ++t)
+                if (outside[t]) *reinterpret_cast<f32x4*>(ring + r * ROWF + 4 * (lane + kWave * t)) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     float acc[TYB][NX];
 #pragma unroll
@@ -249,62 +314,65 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
 #pragma unroll
     for (int x = 0; x < NX; ++x) z[x][0] = z[x][1] = z[x][2] = z[x][3] = 0.f;
 
-    // shifted row index s = r + PH; output row i consumes s in [F*i, F*i+TY)
-    const int s_begin = F * i0;
-    const int s_last = F * (i1 - 1) + TY - 1;                  // last row that carries a tap
-    const int s_end = F * (i1 - 1 + TYB - 1) + F - 1;          // end of the group that retires row i1-1
+    // Shifted HR row index s = r + PH; output row i consumes s in [F*i, F*i+TY).  The chunk is walked in LOCAL
+    // coordinates (il = local output row, sl = local shifted HR row) so that odd chunks can stream bottom-up:
+    // vertically adjacent chunks then read their shared TY-F halo rows at the same moment (L2 / Infinity-Cache
+    // hits instead of a second trip to HBM ~150 us later).  The mirrored walk is the same recurrence with the
+    // tap rows reversed: a = TY-1-a_local.
+    const int nrows = i1 - i0;
+    const bool up = (chunk & 1) != 0;
+    const int s_top = F * (i1 - 1) + TY - 1;                    // bottom-most shifted row of the chunk
+    const int sl_last = F * (nrows - 1) + TY - 1;               // last local row that carries a tap
+    const int sl_end = F * (nrows - 1 + TYB - 1) + F - 1;       // end of the group that retires the last local output row
+    // local rows that are actually staged form one contiguous range [sa, sb]: zero padding skips out-of-image rows
+    int sa = 0, sb = sl_last;
+    if (pad_zero) {
+        if (!up) { sa = max(0, PH - F * i0); sb = min(sl_last, H - 1 + PH - F * i0); }
+        else { sa = max(0, s_top - (H - 1 + PH)); sb = min(sl_last, s_top - PH); }
+    }
 
-    // is HR row for shifted index s needed at all / which image row feeds it
-    auto row_needed = [&](int s) -> bool {
-        if (s > s_last) return false;
-        const int r = s - PH;
-        if (pad_zero && (r < 0 || r >= H)) return false;
-        return true;
-    };
-    f32x4 pre[NLD];
-    auto issue_loads = [&](int s) {
-        const int r = min(max(s - PH, 0), H - 1);
-        const float* __restrict__ rp = img + (long long)r * p.sH;
+    auto issue_row = [&](int sl) {   // sl wave-uniform, sa <= sl <= sb
+        const int s = up ? s_top - sl : F * i0 + sl;
+        const int r = min(max(s - PH, 0), H - 1);               // replicate padding clamps the row
+        const float* __restrict__ rp = img + (long long)r * p.sH + col0;
+        float* slot = ring + ((sl - sa) % R) * ROWF;
 #pragma unroll
         for (int t = 0; t < NLD; ++t) {
-            const int q = lane + kWave * t;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (q < NV) {
-                const int c0 = col0 + 4 * q;
-                if (c0 >= 0 && c0 + 3 < W) {
-                    v = *reinterpret_cast<const f32x4*>(rp + c0);
-                } else if (pad_zero) {
-                    if (c0 + 0 >= 0 && c0 + 0 < W) v.x = rp[c0 + 0];
-                    if (c0 + 1 >= 0 && c0 + 1 < W) v.y = rp[c0 + 1];
-                    if (c0 + 2 >= 0 && c0 + 2 < W) v.z = rp[c0 + 2];
-                    if (c0 + 3 >= 0 && c0 + 3 < W) v.w = rp[c0 + 3];
-                } else {
-                    v.x = rp[min(max(c0 + 0, 0), W - 1)];
-                    v.y = rp[min(max(c0 + 1, 0), W - 1)];
-                    v.z = rp[min(max(c0 + 2, 0), W - 1)];
-                    v.w = rp[min(max(c0 + 3, 0), W - 1)];
-                }
+            if (live[t]) {                                      // wave-uniform: exactly one VMEM instruction
+#if KMSR_ABLATE != 2
+                if (inside[t])                                  // exec mask; LDS dest = slot + 256 t + 4 lane
+                    __builtin_amdgcn_global_load_lds((glb_void_t*)(rp + 4 * (lane + kWave * t)),
+                                                     (lds_void_t*)(slot + 4 * kWave * t), 16, 0, KMSR_DMA_AUX);
+#endif
             }
-            pre[t] = v;
         }
     };
 
-    if (row_needed(s_begin)) issue_loads(s_begin);
-    int g = i0, q = 0;
-    for (int s = s_begin; s <= s_end; ++s) {
-        if (row_needed(s)) {
-            // ---- stage this row: registers -> wave-private LDS row (contiguous 16-B stores)
 #pragma unroll
-            for (int t = 0; t < NLD; ++t) {
-                const int qq = lane + kWave * t;
-                if (qq < NV) *reinterpret_cast<f32x4*>(row + 4 * qq) = pre[t];
-            }
-        }
-        // ---- prefetch the next row while this one is consumed (also when this one was skipped)
-        if (row_needed(s + 1)) issue_loads(s + 1);
-        if (row_needed(s)) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int k = 0; k < R - 1; ++k)
+        if (sa + k <= sb) issue_row(sa + k);
+
+    int gl = 0, q = 0;                                          // local group (= local output row being opened), phase
+    for (int sl = 0; sl <= sl_end; ++sl) {
+        if (sl >= sa && sl <= sb) {
+            if (sl + R - 1 <= sb) issue_row(sl + R - 1);        // refills the slot consumed in the previous iteration
+            wait_vmcnt_le(min(R - 1, sb - sl) * nld_live);      // this row has landed (later rows may still be in flight)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            float* slot = ring + ((sl - sa) % R) * ROWF;
+            if (!pad_zero && any_outside) {
+                // replicate padding: out-of-image float4s take the nearest image pixel of this row (already in LDS)
+#pragma unroll
+                for (int t = 0; t < NLD; ++t) {
+                    if (outside[t]) {
+                        const int c0 = col0 + 4 * (lane + kWave * t);
+                        const float e = slot[(c0 < 0 ? 0 : W - 1) - col0];
+                        *reinterpret_cast<f32x4*>(slot + 4 * (lane + kWave * t)) = f32x4{e, e, e, e};
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             // ---- each lane reads the windows of its NX outputs (neighbour lanes overlap: that is the halo share)
             float win[NX][NWG * G];
 #pragma unroll
@@ -313,7 +381,7 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
 #pragma unroll
                 for (int t = 0; t < NWG; ++t) {
                     using V = typename VecT<G>::type;
-                    const V v = *reinterpret_cast<const V*>(row + base + G * t);
+                    const V v = *reinterpret_cast<const V*>(slot + base + G * t);
                     if constexpr (G == 4) {
                         win[x][4 * t + 0] = v.x; win[x][4 * t + 1] = v.y; win[x][4 * t + 2] = v.z; win[x][4 * t + 3] = v.w;
                     } else if constexpr (G == 2) {
@@ -323,29 +391,43 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
                     }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // ---- fold the row into every open output row (tap row a = F*m + q of slot m)
+            // ---- fold the row into every open output row (local tap row F*m + q of slot m)
 #pragma unroll
             for (int m = 0; m < TYB; ++m) {
-                const int a = F * m + q;
-                const int i = g - m;
-                if (a < TY && i >= i0 && i < i1) {  // wave-uniform
-                    const float* __restrict__ tp = taps + a * TXP;
+                const int al = F * m + q;
+                const int il = gl - m;
+                if (al < TY && il >= 0 && il < nrows) {  // wave-uniform
+                    const float* __restrict__ tp = taps + (up ? TY - 1 - al : al) * TXP;
 #pragma unroll
                     for (int b = 0; b < TX; ++b) {
+#if KMSR_ABLATE == 3
+                        const float kv = 0.01f * (float)(b + 1);
+#else
                         const float kv = tp[b];
+#endif
+#if KMSR_ABLATE == 1
+                        if (b == 0)
+#pragma unroll
+                            for (int x = 0; x < NX; ++x) acc[m][x] += kv;
+#pragma unroll
+                        for (int x = 0; x < NX; ++x) asm volatile("" ::"v"(win[x][OFF + b]));
+#else
 #pragma unroll
                         for (int x = 0; x < NX; ++x) acc[m][x] = fmaf(kv, win[x][OFF + b], acc[m][x]);
+#endif
                     }
                 }
             }
+            // the LDS reads above must retire before a later iteration's DMA overwrites this slot
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         if (++q == F) {
-            // ---- group finished: slot TYB-1 holds output row i = g-(TYB-1), complete
-            const int i = g - (TYB - 1);
-            if (i >= i0 && i < i1) {
-                if (p.noise_mode == KMSR_NOISE_GAUSSIAN && (i & 3) == 0) {
+            // ---- group finished: slot TYB-1 holds local output row il = gl-(TYB-1), complete
+            const int il = gl - (TYB - 1);
+            if (il >= 0 && il < nrows) {
+                const int i = up ? i1 - 1 - il : i0 + il;
+                if (p.noise_mode == KMSR_NOISE_GAUSSIAN && (il == 0 || (i & 3) == (up ? 3 : 0))) {
 #pragma unroll
                     for (int x = 0; x < NX; ++x)
                         eps4(p.seed, p.offset, (unsigned)plane, (unsigned)(i >> 2), (unsigned)(xs0 + lane + kWave * x),
@@ -369,7 +451,7 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
 #pragma unroll
             for (int x = 0; x < NX; ++x) acc[0][x] = 0.f;
             q = 0;
-            ++g;
+            ++gl;
         }
     }
 }
@@ -527,6 +609,19 @@ extern "C" int kmsr_degrade_f32(const kmsr_degrade_desc* d, const float* hr, con
     p.nidx = reinterpret_cast<const long long*>(noise_idx); p.lr = lr;
     p.seed = d->seed; p.offset = d->offset; p.pad_zero = d->pad_mode == KMSR_PAD_ZERO; p.noise_mode = d->noise_mode;
 
+    // Row-chunk height.  It also fixes the summation direction per output row (odd chunks accumulate tap rows
+    // bottom-up), so it is chosen identically for both kernels.
+    const int NX_auto = g.w >= 128 ? 2 : 1;
+    int rows = d->rows_per_chunk;
+    if (rows <= 0) {
+        // chunks tall enough to amortise the (TY-F)-row vertical halo, but enough waves to cover 256 CUs
+        // several times over (measured: 16 rows is the sweet spot at >= 4k waves, profiles/r01)
+        rows = 16;
+        const long long planes_strips = (long long)d->N * d->C * ceil_div(g.w, kWave * NX_auto);
+        while (rows > 4 && planes_strips * ceil_div(g.h, rows) < 4096) rows >>= 1;
+    }
+    rows = std::max(4, rows / 4 * 4);  // the noise stream is generated per 4 output rows
+    p.rows_per_chunk = rows;
     const bool fast = !(d->flags & KMSR_FLAG_FORCE_GENERIC) && fast_eligible(d, g, hr);
     if (!fast && (d->flags & KMSR_FLAG_FORCE_FAST))
         return fail(KMSR_E_UNSUPPORTED, "fast path not available for F=%d taps=%dx%d W=%d", g.F, g.TY, g.TX, d->W);
@@ -538,31 +633,35 @@ extern "C" int kmsr_degrade_f32(const kmsr_degrade_desc* d, const float* hr, con
         return KMSR_OK;
     }
 
-    const int NX = g.w >= 128 ? 2 : 1;
+    int NX = NX_auto;
+    int ring = kRing;
+    if (const char* e = getenv("KMSR_DEGRADE_NX")) NX = atoi(e) == 1 ? 1 : 2;      // tuning overrides
+    if (const char* e = getenv("KMSR_DEGRADE_RING")) ring = atoi(e);
     const int SW = kWave * NX;
     p.n_strips = ceil_div(g.w, SW);
-    int rows = d->rows_per_chunk;
-    if (rows <= 0) {
-        // enough waves to fill 256 CUs x >= 8 waves, but chunks tall enough to amortise the (TY-F)-row halo
-        rows = 64;
-        const long long planes_strips = (long long)d->N * d->C * p.n_strips;
-        while (rows > 8 && planes_strips * ceil_div(g.h, rows) < 8192) rows >>= 1;
-    }
-    rows = std::max(4, rows / 4 * 4);  // the noise stream is generated per 4 output rows
-    p.rows_per_chunk = rows;
     p.n_chunks = ceil_div(g.h, rows);
     const long long units = (long long)d->N * d->C * p.n_strips * p.n_chunks;
     if (units > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "batch too large for one launch");
     p.n_units = (int)units;
     p.n_blocks = ceil_div(p.n_units, kWavesPerBlock);
     const dim3 grid(p.n_blocks), block(kWave * kWavesPerBlock);
-#define X(F_, TY_, TX_, PH_, PW_)                                                                    \
-    if (g.F == F_ && g.TY == TY_ && g.TX == TX_ && g.ph == PH_ && g.pw == PW_) {                     \
-        if (NX == 2) degrade_rowstream_kernel<F_, TY_, TX_, PH_, PW_, 2><<<grid, block, 0, stream>>>(hr, p.taps, sigma, noise, lr, p); \
-        else degrade_rowstream_kernel<F_, TY_, TX_, PH_, PW_, 1><<<grid, block, 0, stream>>>(hr, p.taps, sigma, noise, lr, p);     \
+#define KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, NX_, R_) \
+    degrade_rowstream_kernel<F_, TY_, TX_, PH_, PW_, NX_, R_><<<grid, block, 0, stream>>>(hr, p.taps, sigma, noise, lr, p)
+#define X(F_, TY_, TX_, PH_, PW_)                                                      \
+    if (g.F == F_ && g.TY == TY_ && g.TX == TX_ && g.ph == PH_ && g.pw == PW_) {       \
+        if (NX == 2) {                                                                 \
+            if (ring == 3) KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 2, 3);                  \
+            else if (ring == 6) KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 2, 6);             \
+            else KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 2, 4);                            \
+        } else {                                                                       \
+            if (ring == 3) KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 1, 3);                  \
+            else if (ring == 6) KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 1, 6);             \
+            else KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 1, 4);                            \
+        }                                                                              \
     } else
     KMSR_ROWSTREAM_TABLE(X) { return fail(KMSR_E_UNSUPPORTED, "internal: no instantiation"); }
 #undef X
+#undef KMSR_LAUNCH
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
 }
