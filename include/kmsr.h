@@ -124,6 +124,41 @@ int kmsr_gaussian_eps_f32(float* out, int32_t planes, int32_t h, int32_t w, uint
 int kmsr_noise_crops_f32(const float* geo, const float* den, int32_t C, int32_t H, int32_t W,
                          const int32_t* offs, int32_t n, int32_t crop, float* out, void* stream);
 
+/* ============================================================================================
+ * 3x3 convolution, NCHW fp32, zero padding 1, stride 1 or 2 -- the SR network's conv stack
+ * (head / residual body / upsampler / tail; the reference itself ships no SR model,
+ * the module is build-defined and its oracle is the same module in stock torch ops) and the
+ * reference's own 3x3 stacks: SelectorNet (muti_kernel/train_gemini.py:18-33, stride 2, BN folded by the
+ * caller) and ConditionEncoder (muti_kernel/networks.py:31-38).
+ *
+ * Implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain):
+ *   out[n,co,y,x] = epilogue( sum_{ci,u,v} w[co,ci,u,v] * x[n,ci,y*stride+u-1,x*stride+v-1] )
+ *   epilogue(v)   = v + bias[co];  if relu: max(v,0);  if residual: v + residual[n,co,y,x]
+ *   pixel_shuffle=1 (nn.PixelShuffle(2) fused into the store; Cout % 4 == 0):
+ *       out[n, co/4, 2y + (co/2)%2, 2x + co%2] = epilogue(...)        out is [N,Cout/4,2Ho,2Wo]
+ * Weights are consumed in a packed layout produced once per weight update by kmsr_conv3x3_pack_weights_f32
+ * (a pure permutation + zero padding: [ceil(Cout/64)][ceil(Cin/8)][9][8][64]).
+ * ========================================================================================== */
+typedef struct kmsr_conv3x3_desc {
+    int32_t N, Cin, H, W;    /* input  [N,Cin,H,W] contiguous                                        */
+    int32_t Cout;            /* output [N,Cout,Ho,Wo], Ho = (H-1)/stride+1, Wo = (W-1)/stride+1       */
+    int32_t stride;          /* 1 or 2                                                               */
+    int32_t relu;            /* 0/1                                                                  */
+    int32_t pixel_shuffle;   /* 0/1 (stride must be 1)                                               */
+    uint32_t flags;          /* reserved, 0                                                          */
+} kmsr_conv3x3_desc;
+
+/* number of floats in the packed weight buffer for (Cin, Cout) */
+size_t kmsr_conv3x3_packed_weight_floats(int32_t Cin, int32_t Cout);
+/* w [Cout,Cin,3,3] -> packed.  transpose_flip=1 packs the weights of the data-gradient convolution instead
+ * (w'[ci,co,u,v] = w[co,ci,2-u,2-v]; then Cin/Cout of the *packed* conv are swapped by the caller).          */
+int kmsr_conv3x3_pack_weights_f32(const float* w, int32_t Cin, int32_t Cout, int32_t transpose_flip, float* packed,
+                                  void* stream);
+int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w,
+                         const float* bias,      /* [Cout] or NULL                                  */
+                         const float* residual,  /* out-shaped or NULL (not with pixel_shuffle)      */
+                         float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

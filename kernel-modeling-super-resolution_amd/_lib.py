@@ -35,6 +35,15 @@ class DegradeDesc(C.Structure):
     ]
 
 
+class Conv3x3Desc(C.Structure):
+    """struct kmsr_conv3x3_desc (include/kmsr.h)"""
+    _fields_ = [
+        ("N", C.c_int32), ("Cin", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("Cout", C.c_int32), ("stride", C.c_int32), ("relu", C.c_int32), ("pixel_shuffle", C.c_int32),
+        ("flags", C.c_uint32),
+    ]
+
+
 _lib = None
 
 # every symbol include/kmsr.h declares: (name, restype, argtypes)
@@ -49,6 +58,9 @@ SYMBOLS = {
     "kmsr_degrade_f32": (C.c_int, [C.POINTER(DegradeDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kmsr_gaussian_eps_f32": (C.c_int, [_vp, _i32, _i32, _i32, _u64, _u32, _vp]),
     "kmsr_noise_crops_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "kmsr_conv3x3_packed_weight_floats": (_sz, [_i32, _i32]),
+    "kmsr_conv3x3_pack_weights_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "kmsr_conv3x3_fwd_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 

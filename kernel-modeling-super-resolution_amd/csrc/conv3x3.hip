@@ -1,0 +1,284 @@
+// 3x3 convolution as an implicit GEMM on the gfx950 fp32 matrix cores (see include/kmsr.h for semantics).
+//
+//   D[co, px] += A[co, k] * B[k, px],  k = (tap, ci),  one v_mfma_f32_32x32x2_f32 per 32 co x 32 px x 2 ci
+//   A = weights  (lane l holds A[co = l&31][k = l>>5]),  B = input pixels (lane l holds B[k = l>>5][px = l&31])
+//   D: lane l holds px = l&31 and 16 output channels (reg&3) + 8*(reg>>2) + 4*(l>>5)  -> NCHW stores are two
+//      128-byte row segments per instruction, and a 2x2 PixelShuffle group (4 consecutive co) sits in 4
+//      consecutive registers of ONE lane, so the shuffle is fused into the store as two 8-byte writes.
+//
+// Block = 4 waves, output tile 8 rows x 32 cols x 64 output channels; wave w owns rows 2w, 2w+1 (2x2 MFMA
+// blocks, 64 accumulator VGPRs).  Input channels stream through LDS in chunks of 8 (input halo tile
+// 8 x 10 x 34 + the chunk's 9 x 8 x 64 weights = 30 KB), double buffered: the next chunk's global loads are
+// issued before the current chunk's 144 MFMAs per wave and written to the other buffer after them, one
+// __syncthreads per chunk.  Two blocks per CU (2 waves per SIMD) overlap one block's barrier with the other's MFMAs.
+#include "kmsr_common.h"
+
+#include <algorithm>
+
+namespace kmsr {
+namespace {
+
+constexpr int CK = 8;     // input channels per LDS chunk
+constexpr int TH = 8;     // output tile rows per block
+constexpr int TW = 32;    // output tile cols per block (= MFMA N)
+constexpr int COB = 64;   // output channels per block (2 MFMA M blocks)
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+struct ConvParams {
+    const float* x;
+    const float* wpk;
+    const float* bias;
+    const float* res;
+    float* out;
+    int N, Cin, H, W, Cout, Ho, Wo;
+    int tiles_x, tiles, cgs, nchunks, relu, n_blocks;
+};
+
+template <int S>
+struct ConvCfg {
+    static constexpr int IH = (TH - 1) * S + 3;
+    static constexpr int IW = (TW - 1) * S + 3;
+    static constexpr int IWP = (IW + 3) / 4 * 4;
+    static constexpr int IN_FLOATS = CK * IH * IWP;
+    static constexpr int W_FLOATS = 9 * CK * COB;
+    static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
+    static constexpr int IN_ELEMS = CK * IH * IW;
+    static constexpr int NIN = (IN_ELEMS + 255) / 256;
+    static constexpr int NW4 = (W_FLOATS / 4 + 255) / 256;
+};
+
+// packed[cg][chunk][tap][c][co]  <-  w[co_g][ci_g][tap]   (zero padded); transpose_flip: data-gradient weights
+__global__ void pack_weights_kernel(const float* __restrict__ w, int Cin, int Cout, int tf, float* __restrict__ packed,
+                                    int nchunks, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(idx % COB);
+        const int c = (int)((idx / COB) % CK);
+        const int tap = (int)((idx / (COB * CK)) % 9);
+        const int chunk = (int)((idx / (COB * CK * 9)) % nchunks);
+        const int cg = (int)(idx / ((long long)COB * CK * 9 * nchunks));
+        const int cop = cg * COB + co, cip = chunk * CK + c;      // channel indices of the PACKED convolution
+        const int CinP = tf ? Cout : Cin, CoutP = tf ? Cin : Cout;
+        float v = 0.f;
+        if (cop < CoutP && cip < CinP) {
+            if (!tf) v = w[((long long)cop * Cin + cip) * 9 + tap];
+            else v = w[((long long)cip * Cin + cop) * 9 + (8 - tap)];  // w'[co'][ci'][u][v] = w[ci'][co'][2-u][2-v]
+        }
+        packed[idx] = v;
+    }
+}
+
+template <int S, bool PS>
+__global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __restrict__ xg, const float* __restrict__ wpk,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ res, float* __restrict__ out,
+                                                              ConvParams p) {
+    using Cfg = ConvCfg<S>;
+    constexpr int IH = Cfg::IH, IW = Cfg::IW, IWP = Cfg::IWP, IN_FLOATS = Cfg::IN_FLOATS, W_FLOATS = Cfg::W_FLOATS;
+    constexpr int BUF = Cfg::BUF_FLOATS, IN_ELEMS = Cfg::IN_ELEMS, NIN = Cfg::NIN, NW4 = Cfg::NW4;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // XCD-aware remap of the linear block id: blocks that share an XCD (id % 8) get a contiguous range of tiles,
+    // so neighbouring tiles (shared halo) and all cout groups of an image meet in one L2.
+    const int nb = p.n_blocks, bq = nb >> 3, br = nb & 7, xcd = blockIdx.x & 7;
+    int bid = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (blockIdx.x >> 3);
+    const int tile = bid % p.tiles;
+    bid /= p.tiles;
+    const int cg = bid % p.cgs;
+    const int n = bid / p.cgs;
+    const int ty0 = (tile / p.tiles_x) * TH, tx0 = (tile % p.tiles_x) * TW;
+    const int H = p.H, W = p.W;
+    const long long HW = (long long)H * W;
+
+    // ---- staging map of the input halo tile (same for every chunk)
+    int goff[NIN];
+#pragma unroll
+    for (int t = 0; t < NIN; ++t) {
+        const int e = tid + 256 * t;
+        const int c = e / (IH * IW), rem = e - c * (IH * IW), r = rem / IW, col = rem - r * IW;
+        const int gy = ty0 * S - 1 + r, gx = tx0 * S - 1 + col;
+        const bool ok = e < IN_ELEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[t] = ok ? (int)(c * HW + (long long)gy * W + gx) : -1;
+    }
+    const float* __restrict__ xn = xg + (long long)n * p.Cin * HW;
+    const float* __restrict__ wcg = wpk + (long long)cg * p.nchunks * W_FLOATS;
+
+    float xin[NIN];
+    f32x4 wreg[NW4];
+    auto load_chunk = [&](int chunk) {
+        const float* __restrict__ xc = xn + (long long)chunk * CK * HW;
+        const int cin_left = p.Cin - chunk * CK;
+#pragma unroll
+        for (int t = 0; t < NIN; ++t) {
+            const int c = (tid + 256 * t) / (IH * IW);
+            const bool ok = goff[t] >= 0 && c < cin_left;
+            const float v = xc[ok ? goff[t] : 0];   // unconditional load from a safe address + select: no branch, no
+            xin[t] = ok ? v : 0.f;                  // per-load wait (zero padding and channel padding come from here)
+        }
+        const f32x4* __restrict__ wc = reinterpret_cast<const f32x4*>(wcg + (long long)chunk * W_FLOATS);
+#pragma unroll
+        for (int t = 0; t < NW4; ++t) {
+            const int e4 = tid + 256 * t;
+            if (e4 < W_FLOATS / 4) wreg[t] = wc[e4];
+        }
+    };
+    auto store_chunk = [&](int b) {
+        float* inb = lds + b * BUF;
+        float* wb = inb + IN_FLOATS;
+#pragma unroll
+        for (int t = 0; t < NIN; ++t) {
+            const int e = tid + 256 * t;
+            const int c = e / (IH * IW), rem = e - c * (IH * IW), r = rem / IW, col = rem - r * IW;
+            if (e < IN_ELEMS) inb[(c * IH + r) * IWP + col] = xin[t];
+        }
+#pragma unroll
+        for (int t = 0; t < NW4; ++t) {
+            const int e4 = tid + 256 * t;
+            if (e4 < W_FLOATS / 4) reinterpret_cast<f32x4*>(wb)[e4] = wreg[t];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+
+    const int aoff = half * COB + l32;                                        // + (tap*CK + 2*kp)*COB + 32*mt
+    const int boff = half * (IH * IWP) + (2 * wv * S) * IWP + l32 * S;        // + (2*kp)*IH*IWP + (nt*S + dy)*IWP + dx
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const int b = chunk & 1;
+        if (chunk + 1 < p.nchunks) load_chunk(chunk + 1);   // global loads in flight under the MFMAs below
+        const float* inb = lds + b * BUF;
+        const float* wb = inb + IN_FLOATS;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+            for (int kp = 0; kp < CK / 2; ++kp) {
+                const float a0 = wb[aoff + (tap * CK + 2 * kp) * COB];
+                const float a1 = wb[aoff + (tap * CK + 2 * kp) * COB + 32];
+                const float b0 = inb[boff + (2 * kp) * (IH * IWP) + dy * IWP + dx];
+                const float b1 = inb[boff + (2 * kp) * (IH * IWP) + (S + dy) * IWP + dx];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        if (chunk + 1 < p.nchunks) store_chunk(b ^ 1);      // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, ReLU, residual, (PixelShuffle) store
+    const int x = tx0 + l32;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int y = ty0 + 2 * wv + nt;
+            if (y >= p.Ho || x >= p.Wo) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co0 = cg * COB + mt * 32 + 8 * g + 4 * half;   // 4 consecutive channels: regs 4g .. 4g+3
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + r;
+                    float t = acc[mt][nt][4 * g + r];
+                    if (co < p.Cout) {
+                        if (bias) t += bias[co];
+                        if (p.relu) t = fmaxf(t, 0.f);
+                    }
+                    v[r] = t;
+                }
+                if constexpr (PS) {
+                    // out[n, co/4, 2y + (co/2)%2, 2x + co%2]; co0 % 4 == 0
+                    if (co0 < p.Cout) {
+                        const long long W2 = 2ll * p.Wo;
+                        float* o = out + (((long long)n * (p.Cout >> 2) + (co0 >> 2)) * (2ll * p.Ho) + 2 * y) * W2 + 2 * x;
+                        *reinterpret_cast<f32x2*>(o) = f32x2{v[0], v[1]};
+                        *reinterpret_cast<f32x2*>(o + W2) = f32x2{v[2], v[3]};
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = co0 + r;
+                        if (co < p.Cout) {
+                            const long long idx = (((long long)n * p.Cout + co) * p.Ho + y) * p.Wo + x;
+                            float t = v[r];
+                            if (res) t += res[idx];
+                            out[idx] = t;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+}  // namespace kmsr
+
+using namespace kmsr;
+
+extern "C" size_t kmsr_conv3x3_packed_weight_floats(int32_t Cin, int32_t Cout) {
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)ceil_div(Cout, COB) * ceil_div(Cin, CK) * 9 * CK * COB;
+}
+
+extern "C" int kmsr_conv3x3_pack_weights_f32(const float* w, int32_t Cin, int32_t Cout, int32_t transpose_flip,
+                                             float* packed, void* stream) {
+    if (!w || !packed || Cin <= 0 || Cout <= 0) return fail(KMSR_E_BADARG, "pack_weights: bad argument");
+    const int CinP = transpose_flip ? Cout : Cin, CoutP = transpose_flip ? Cin : Cout;
+    const int nchunks = ceil_div(CinP, CK);
+    const long long total = (long long)ceil_div(CoutP, COB) * nchunks * 9 * CK * COB;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    pack_weights_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(w, Cin, Cout, transpose_flip, packed,
+                                                                             nchunks, total);
+    KMSR_HIP_CHECK(hipGetLastError());
+    return KMSR_OK;
+}
+
+extern "C" int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w,
+                                    const float* bias, const float* residual, float* out, void* stream_) {
+    if (!d) return fail(KMSR_E_BADARG, "null descriptor");
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return fail(KMSR_E_BADARG, "bad conv shape");
+    if (d->stride != 1) return fail(KMSR_E_UNSUPPORTED, "conv3x3 stride %d not implemented yet", d->stride);
+    if (d->pixel_shuffle && (d->Cout % 4)) return fail(KMSR_E_SHAPE, "pixel_shuffle needs Cout %% 4 == 0 (Cout=%d)", d->Cout);
+    if (d->pixel_shuffle && residual) return fail(KMSR_E_BADARG, "residual is not supported together with pixel_shuffle");
+    if (!x || !packed_w || !out) return fail(KMSR_E_BADARG, "null tensor pointer");
+    ConvParams p{};
+    p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
+    p.Ho = (d->H - 1) / d->stride + 1;
+    p.Wo = (d->W - 1) / d->stride + 1;
+    if ((long long)d->Cin * d->H * d->W >= (1ll << 31)) return fail(KMSR_E_UNSUPPORTED, "per-image input exceeds 2^31 elements");
+    p.tiles_x = ceil_div(p.Wo, TW);
+    p.tiles = p.tiles_x * ceil_div(p.Ho, TH);
+    p.cgs = ceil_div(d->Cout, COB);
+    p.nchunks = ceil_div(d->Cin, CK);
+    p.relu = d->relu;
+    const long long nblocks = (long long)p.tiles * p.cgs * d->N;
+    if (nblocks > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv grid too large");
+    p.n_blocks = (int)nblocks;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (d->pixel_shuffle)
+        conv3x3_mfma_kernel<1, true><<<p.n_blocks, 256, 0, stream>>>(x, packed_w, bias, residual, out, p);
+    else
+        conv3x3_mfma_kernel<1, false><<<p.n_blocks, 256, 0, stream>>>(x, packed_w, bias, residual, out, p);
+    KMSR_HIP_CHECK(hipGetLastError());
+    return KMSR_OK;
+}
