@@ -30,6 +30,19 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 MFMA / vector peak
 
 
+def host_cores():
+    """CPU cores this process may really use: min(affinity, cgroup cpu.max quota) -- the GPU box exposes 256 logical
+    CPUs but a 16-core quota, and oversubscribing OpenMP / ATen thread pools on it is far slower than 16 threads."""
+    n = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def synth_hr(n, c, h, w, device, seed):
     """Synthetic 'Landsat-shaped' TOA radiance tiles: U(20,100), fp32, NaN-free."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -79,8 +92,7 @@ class DegradeWorkload:
     def cpu_baseline(self, budget_s=12.0):
         """The oracle (CPU restatement of train_gemini.py:124-138) on a bounded sample of the same workload."""
         import oracle
-        cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
-        cores = oracle.set_threads(cores)
+        cores = oracle.set_threads(host_cores())
         hr = self.hr[:2].cpu().numpy()
         kern = self.bank[self.kid[:2].long()].cpu().numpy()
         sig = self.sigma[self.kid[:2].long()].cpu().numpy().reshape(-1)
@@ -173,7 +185,7 @@ class DegradeSRWorkload:
         (ATen CPU convs -- the way the reference itself runs its conv stacks on a CPU), 1 patch at a time."""
         import oracle
         from oracle.sr_torch import SRNetTorch
-        cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+        cores = host_cores()
         oracle.set_threads(cores)
         torch.set_num_threads(cores)
         ref = SRNetTorch(self.C, 64, 16, 4).eval()

@@ -137,7 +137,8 @@ int kmsr_noise_crops_f32(const float* geo, const float* den, int32_t C, int32_t 
  *   pixel_shuffle=1 (nn.PixelShuffle(2) fused into the store; Cout % 4 == 0):
  *       out[n, co/4, 2y + (co/2)%2, 2x + co%2] = epilogue(...)        out is [N,Cout/4,2Ho,2Wo]
  * Weights are consumed in a packed layout produced once per weight update by kmsr_conv3x3_pack_weights_f32
- * (a pure permutation + zero padding: [ceil(Cout/64)][ceil(Cin/8)][9][8][64]).
+ * (a pure permutation + zero padding: [ceil(Cout/64)][ceil(Cin/8)][9][8][64]; for Cout <= 8, which is served by a
+ * direct VALU kernel instead of MFMA tiles that would be mostly padding, [ceil(Cin/4)*4][9][Cout]).
  * ========================================================================================== */
 typedef struct kmsr_conv3x3_desc {
     int32_t N, Cin, H, W;    /* input  [N,Cin,H,W] contiguous                                        */

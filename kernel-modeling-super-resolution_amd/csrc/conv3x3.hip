@@ -230,6 +230,149 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __res
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Small-Cout direct kernel (Cout <= 8: the SR tail conv F -> bands).  With 3..7 output channels an MFMA
+// tile would be >= 78 % zero padding, while the fp32 VALU pipe has the same 157 TF peak, so this path is plain
+// v_fma: each thread owns 4 consecutive pixels x COUT channels, the input halo tile streams through LDS in
+// chunks of 4 channels (double buffered), and the weights are wave-uniform -> scalar loads, SGPR operands.
+// Packed layout for this path: [ceil(Cin/4)*4][9][COUT].
+// ------------------------------------------------------------------------------------------------
+constexpr int SCK = 4;            // input channels per LDS chunk
+constexpr int STH = 16, STW = 64; // output tile
+constexpr int SIH = STH + 2, SIW = STW + 2, SIWP = 68;
+
+template <int COUT>
+__global__ void __launch_bounds__(256) conv3x3_smallco_kernel(const float* __restrict__ xg, const float* __restrict__ wpk,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ res, float* __restrict__ out,
+                                                               ConvParams p) {
+    constexpr int IN_FLOATS = SCK * SIH * SIWP;
+    constexpr int IN_ELEMS = SCK * SIH * SIW;
+    constexpr int NIN = (IN_ELEMS + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float lds[2 * IN_FLOATS];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    int bid = blockIdx.x;
+    const int tile = bid % p.tiles;
+    const int n = bid / p.tiles;
+    const int ty0 = (tile / p.tiles_x) * STH, tx0 = (tile % p.tiles_x) * STW;
+    const int H = p.H, W = p.W;
+    const long long HW = (long long)H * W;
+
+    int goff[NIN];
+#pragma unroll
+    for (int t = 0; t < NIN; ++t) {
+        const int e = tid + 256 * t;
+        const int c = e / (SIH * SIW), rem = e - c * (SIH * SIW), r = rem / SIW, col = rem - r * SIW;
+        const int gy = ty0 - 1 + r, gx = tx0 - 1 + col;
+        const bool ok = e < IN_ELEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[t] = ok ? (int)(c * HW + (long long)gy * W + gx) : -1;
+    }
+    const float* __restrict__ xn = xg + (long long)n * p.Cin * HW;
+    float xin[NIN];
+    auto load_chunk = [&](int chunk) {
+        const float* __restrict__ xc = xn + (long long)chunk * SCK * HW;
+        const int cin_left = p.Cin - chunk * SCK;
+#pragma unroll
+        for (int t = 0; t < NIN; ++t) {
+            const int c = (tid + 256 * t) / (SIH * SIW);
+            const bool ok = goff[t] >= 0 && c < cin_left;
+            const float v = xc[ok ? goff[t] : 0];
+            xin[t] = ok ? v : 0.f;
+        }
+    };
+    auto store_chunk = [&](int b) {
+        float* inb = lds + b * IN_FLOATS;
+#pragma unroll
+        for (int t = 0; t < NIN; ++t) {
+            const int e = tid + 256 * t;
+            const int c = e / (SIH * SIW), rem = e - c * (SIH * SIW), r = rem / SIW, col = rem - r * SIW;
+            if (e < IN_ELEMS) inb[(c * SIH + r) * SIWP + col] = xin[t];
+        }
+    };
+
+    float acc[COUT][4];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) acc[co][px] = 0.f;
+
+    const int nchunks = (p.Cin + SCK - 1) / SCK;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int b = chunk & 1;
+        if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+        const float* inb = lds + b * IN_FLOATS + ty * SIWP + 4 * tx;
+        const float* __restrict__ wc = wpk + (long long)chunk * SCK * 9 * COUT;   // wave-uniform
+#pragma unroll
+        for (int c = 0; c < SCK; ++c) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const float* rowp = inb + (c * SIH + dy) * SIWP;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(rowp);
+                const f32x2 bb = *reinterpret_cast<const f32x2*>(rowp + 4);
+                const float v[6] = {a.x, a.y, a.z, a.w, bb.x, bb.y};
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) {
+                        const float wv = wc[(c * 9 + dy * 3 + dx) * COUT + co];
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) acc[co][px] = fmaf(wv, v[px + dx], acc[co][px]);
+                    }
+                }
+            }
+        }
+        if (chunk + 1 < nchunks) store_chunk(b ^ 1);
+        __syncthreads();
+    }
+
+    const int y = ty0 + ty, x = tx0 + 4 * tx;
+    if (y < p.Ho) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float bv = bias ? bias[co] : 0.f;
+            const long long base = (((long long)n * COUT + co) * p.Ho + y) * p.Wo + x;
+            float v[4];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                v[px] = acc[co][px] + bv;
+                if (p.relu) v[px] = fmaxf(v[px], 0.f);
+            }
+            if (x + 3 < p.Wo && (p.Wo & 3) == 0) {
+                if (res) {
+                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(res + base);
+                    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
+                *reinterpret_cast<f32x4*>(out + base) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int px = 0; px < 4; ++px)
+                    if (x + px < p.Wo) out[base + px] = v[px] + (res ? res[base + px] : 0.f);
+            }
+        }
+    }
+}
+
+// packed[ci][tap][co] <- w[co][ci][tap], ci zero-padded to a multiple of SCK
+__global__ void pack_weights_smallco_kernel(const float* __restrict__ w, int Cin, int Cout, int tf,
+                                            float* __restrict__ packed, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int CinP = tf ? Cout : Cin, CoutP = tf ? Cin : Cout;
+        const int co = (int)(idx % CoutP);
+        const int tap = (int)((idx / CoutP) % 9);
+        const int ci = (int)(idx / ((long long)CoutP * 9));
+        float v = 0.f;
+        if (ci < CinP) v = !tf ? w[((long long)co * Cin + ci) * 9 + tap] : w[((long long)ci * Cin + co) * 9 + (8 - tap)];
+        packed[idx] = v;
+    }
+}
+
+constexpr int kSmallCoMax = 8;
+
 }  // namespace
 }  // namespace kmsr
 
@@ -237,6 +380,7 @@ using namespace kmsr;
 
 extern "C" size_t kmsr_conv3x3_packed_weight_floats(int32_t Cin, int32_t Cout) {
     if (Cin <= 0 || Cout <= 0) return 0;
+    if (Cout <= kSmallCoMax) return (size_t)round_up(Cin, SCK) * 9 * Cout;   // small-Cout direct kernel layout
     return (size_t)ceil_div(Cout, COB) * ceil_div(Cin, CK) * 9 * CK * COB;
 }
 
@@ -244,6 +388,14 @@ extern "C" int kmsr_conv3x3_pack_weights_f32(const float* w, int32_t Cin, int32_
                                              float* packed, void* stream) {
     if (!w || !packed || Cin <= 0 || Cout <= 0) return fail(KMSR_E_BADARG, "pack_weights: bad argument");
     const int CinP = transpose_flip ? Cout : Cin, CoutP = transpose_flip ? Cin : Cout;
+    if (CoutP <= kSmallCoMax) {
+        const long long total = (long long)round_up(CinP, SCK) * 9 * CoutP;
+        const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        pack_weights_smallco_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(w, Cin, Cout, transpose_flip,
+                                                                                        packed, total);
+        KMSR_HIP_CHECK(hipGetLastError());
+        return KMSR_OK;
+    }
     const int nchunks = ceil_div(CinP, CK);
     const long long total = (long long)ceil_div(CoutP, COB) * nchunks * 9 * CK * COB;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
@@ -266,6 +418,22 @@ extern "C" int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, 
     p.Ho = (d->H - 1) / d->stride + 1;
     p.Wo = (d->W - 1) / d->stride + 1;
     if ((long long)d->Cin * d->H * d->W >= (1ll << 31)) return fail(KMSR_E_UNSUPPORTED, "per-image input exceeds 2^31 elements");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (d->Cout <= kSmallCoMax) {
+        if (d->pixel_shuffle) return fail(KMSR_E_UNSUPPORTED, "pixel_shuffle with Cout <= %d is not implemented", kSmallCoMax);
+        p.tiles_x = ceil_div(p.Wo, STW);
+        p.tiles = p.tiles_x * ceil_div(p.Ho, STH);
+        p.relu = d->relu;
+        const long long nb = (long long)p.tiles * d->N;
+        if (nb > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv grid too large");
+        switch (d->Cout) {
+#define KMSR_SC(C_) case C_: conv3x3_smallco_kernel<C_><<<(int)nb, 256, 0, stream>>>(x, packed_w, bias, residual, out, p); break;
+            KMSR_SC(1) KMSR_SC(2) KMSR_SC(3) KMSR_SC(4) KMSR_SC(5) KMSR_SC(6) KMSR_SC(7) KMSR_SC(8)
+#undef KMSR_SC
+        }
+        KMSR_HIP_CHECK(hipGetLastError());
+        return KMSR_OK;
+    }
     p.tiles_x = ceil_div(p.Wo, TW);
     p.tiles = p.tiles_x * ceil_div(p.Ho, TH);
     p.cgs = ceil_div(d->Cout, COB);
@@ -274,7 +442,6 @@ extern "C" int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, 
     const long long nblocks = (long long)p.tiles * p.cgs * d->N;
     if (nblocks > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv grid too large");
     p.n_blocks = (int)nblocks;
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (d->pixel_shuffle)
         conv3x3_mfma_kernel<1, true><<<p.n_blocks, 256, 0, stream>>>(x, packed_w, bias, residual, out, p);
     else

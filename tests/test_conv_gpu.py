@@ -47,7 +47,7 @@ CASES = [
     (1, 64, 24, 40, 256, True, False, False, True),     # upsampler: 4 cout groups + fused PixelShuffle
     (1, 7, 50, 50, 100, True, True, True, False),       # 7 bands, Cout not a multiple of 32/64
     (3, 20, 9, 31, 12, True, False, True, False),       # Cin spans 3 chunks with a partial one, tiny image
-    (1, 16, 1, 1, 8, True, True, False, True),          # 1x1 image, PixelShuffle
+    (1, 16, 1, 1, 16, True, True, False, True),         # 1x1 image, PixelShuffle
 ]
 
 
@@ -101,6 +101,9 @@ def test_conv3x3_errors(gpu_device):
     assert lib.kmsr_conv3x3_fwd_f32(d, L.ptr(x), L.ptr(pw), None, None, L.ptr(x), None) == L.KMSR_E_UNSUPPORTED
     d.stride = 1
     assert lib.kmsr_conv3x3_fwd_f32(d, None, L.ptr(pw), None, None, L.ptr(x), None) == L.KMSR_E_BADARG
+    # Cout <= 8 is served by the direct VALU kernel, which has no fused PixelShuffle (never needed: shuffle convs have 4F channels)
+    with pytest.raises(NotImplementedError):
+        conv3x3(x, pack_conv3x3_weight(torch.zeros(8, 8, 3, 3).cuda()), 8, pixel_shuffle=True)
 
 
 @pytest.mark.parametrize("colors,feats,blocks,scale,shape", [(3, 64, 2, 4, (2, 3, 40, 56)), (5, 32, 3, 2, (1, 5, 33, 31)),
