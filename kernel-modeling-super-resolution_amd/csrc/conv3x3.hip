@@ -12,8 +12,12 @@
 // issued before the current chunk's 144 MFMAs per wave and written to the other buffer after them, one
 // __syncthreads per chunk.  Two blocks per CU (2 waves per SIMD) overlap one block's barrier with the other's MFMAs.
 #include "kmsr_common.h"
+#ifndef KMSR_CONV_ABLATE
+#define KMSR_CONV_ABLATE 0  // diagnostic builds only: 1 = no global loads in the k-loop, 2 = no MFMA, 3 = no LDS restage
+#endif
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace kmsr {
 namespace {
@@ -22,6 +26,8 @@ constexpr int CK = 8;     // input channels per LDS chunk
 constexpr int TH = 8;     // output tile rows per block
 constexpr int TW = 32;    // output tile cols per block (= MFMA N)
 constexpr int COB = 64;   // output channels per block (2 MFMA M blocks)
+constexpr int kFetchTap = 1;    // the next chunk's global loads are issued before this tap (after the first tap's 16 MFMAs)
+constexpr int kRestageTap = 7;  // ... and written to the other LDS buffer before this tap (of 9)
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -110,9 +116,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __res
     const float* __restrict__ xn = xg + (long long)n * p.Cin * HW;
     const float* __restrict__ wcg = wpk + (long long)cg * p.nchunks * W_FLOATS;
 
-    float xin[NIN];
-    f32x4 wreg[NW4];
-    auto load_chunk = [&](int chunk) {
+    // One register staging set: the next chunk's global loads are ISSUED after the first tap's MFMAs (their ~80
+    // address/load instructions then issue in the shadow of the matrix pipe instead of ahead of it) and are written
+    // to the other LDS buffer before tap kRestageTap of the same phase.
+    float xinA[NIN];
+    f32x4 wregA[NW4];
+    auto load_chunk = [&](int chunk, float (&xin)[NIN], f32x4 (&wreg)[NW4]) {
         const float* __restrict__ xc = xn + (long long)chunk * CK * HW;
         const int cin_left = p.Cin - chunk * CK;
 #pragma unroll
@@ -129,7 +138,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __res
             if (e4 < W_FLOATS / 4) wreg[t] = wc[e4];
         }
     };
-    auto store_chunk = [&](int b) {
+    auto store_chunk = [&](int b, const float (&xin)[NIN], const f32x4 (&wreg)[NW4]) {
         float* inb = lds + b * BUF;
         float* wb = inb + IN_FLOATS;
 #pragma unroll
@@ -156,80 +165,112 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __res
     const int aoff = half * COB + l32;                                        // + (tap*CK + 2*kp)*COB + 32*mt
     const int boff = half * (IH * IWP) + (2 * wv * S) * IWP + l32 * S;        // + (2*kp)*IH*IWP + (nt*S + dy)*IWP + dx
 
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        const int b = chunk & 1;
-        if (chunk + 1 < p.nchunks) load_chunk(chunk + 1);   // global loads in flight under the MFMAs below
+    // one chunk: 9 taps x 4 channel pairs x (2x2) MFMAs out of LDS buffer b
+    auto mma_chunk = [&](int b, auto&& fetch, auto&& restage) {
         const float* inb = lds + b * BUF;
         const float* wb = inb + IN_FLOATS;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
+            if (tap == kFetchTap) fetch();
+            if (tap == kRestageTap) restage();
 #pragma unroll
             for (int kp = 0; kp < CK / 2; ++kp) {
                 const float a0 = wb[aoff + (tap * CK + 2 * kp) * COB];
                 const float a1 = wb[aoff + (tap * CK + 2 * kp) * COB + 32];
                 const float b0 = inb[boff + (2 * kp) * (IH * IWP) + dy * IWP + dx];
                 const float b1 = inb[boff + (2 * kp) * (IH * IWP) + (S + dy) * IWP + dx];
+#if KMSR_CONV_ABLATE == 2
+                asm volatile("" ::"v"(a0), "v"(a1), "v"(b0), "v"(b1));
+#else
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#endif
             }
         }
-        if (chunk + 1 < p.nchunks) store_chunk(b ^ 1);      // the other buffer was last read before the previous barrier
+    };
+
+    const int nch = p.nchunks;
+    load_chunk(0, xinA, wregA);
+    store_chunk(0, xinA, wregA);
+    __syncthreads();
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const int b = chunk & 1;
+        const bool more = chunk + 1 < nch;   // block-uniform
+        mma_chunk(b, [&] { if (more) load_chunk(chunk + 1, xinA, wregA); },
+                  [&] { if (more) store_chunk(b ^ 1, xinA, wregA); });   // the other buffer was last read before the previous barrier
         __syncthreads();
     }
 
-    // ---- epilogue: bias, ReLU, residual, (PixelShuffle) store
+    // ---- epilogue: bias, ReLU, residual, (PixelShuffle) store.  No per-element branches around loads: the bias goes
+    //      through LDS (one 16-byte read per 4 channels), residuals are fetched 16 at a time from clamped-safe
+    //      addresses before any of them is consumed, so the block pays one memory round trip per 16 outputs, not 16.
+    float* sbias = lds;   // all MFMA reads of the staging buffers retired at the last barrier
+    if (tid < COB) {
+        const int co = cg * COB + tid;
+        sbias[tid] = (bias && co < p.Cout) ? bias[co] : 0.f;
+    }
+    __syncthreads();
     const int x = tx0 + l32;
+    const bool xok = x < p.Wo;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int y = ty0 + 2 * wv + nt;
-            if (y >= p.Ho || x >= p.Wo) continue;
+            const bool pok = xok && y < p.Ho;
+            float v[16];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int co0 = cg * COB + mt * 32 + 8 * g + 4 * half;   // 4 consecutive channels: regs 4g .. 4g+3
-                float v[4];
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + mt * 32 + 8 * g + 4 * half);
+                v[4 * g + 0] = acc[mt][nt][4 * g + 0] + b4.x;
+                v[4 * g + 1] = acc[mt][nt][4 * g + 1] + b4.y;
+                v[4 * g + 2] = acc[mt][nt][4 * g + 2] + b4.z;
+                v[4 * g + 3] = acc[mt][nt][4 * g + 3] + b4.w;
+            }
+            if (p.relu) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + r;
-                    float t = acc[mt][nt][4 * g + r];
-                    if (co < p.Cout) {
-                        if (bias) t += bias[co];
-                        if (p.relu) t = fmaxf(t, 0.f);
-                    }
-                    v[r] = t;
-                }
-                if constexpr (PS) {
-                    // out[n, co/4, 2y + (co/2)%2, 2x + co%2]; co0 % 4 == 0
-                    if (co0 < p.Cout) {
-                        const long long W2 = 2ll * p.Wo;
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if constexpr (PS) {
+                // out[n, co/4, 2y + (co/2)%2, 2x + co%2]; the 4 registers of group g are one 2x2 output block
+                const long long W2 = 2ll * p.Wo;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co0 = cg * COB + mt * 32 + 8 * g + 4 * half;
+                    if (pok && co0 < p.Cout) {
                         float* o = out + (((long long)n * (p.Cout >> 2) + (co0 >> 2)) * (2ll * p.Ho) + 2 * y) * W2 + 2 * x;
-                        *reinterpret_cast<f32x2*>(o) = f32x2{v[0], v[1]};
-                        *reinterpret_cast<f32x2*>(o + W2) = f32x2{v[2], v[3]};
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int co = co0 + r;
-                        if (co < p.Cout) {
-                            const long long idx = (((long long)n * p.Cout + co) * p.Ho + y) * p.Wo + x;
-                            float t = v[r];
-                            if (res) t += res[idx];
-                            out[idx] = t;
-                        }
+                        *reinterpret_cast<f32x2*>(o) = f32x2{v[4 * g + 0], v[4 * g + 1]};
+                        *reinterpret_cast<f32x2*>(o + W2) = f32x2{v[4 * g + 2], v[4 * g + 3]};
                     }
                 }
+            } else {
+                const long long plane = (long long)p.Ho * p.Wo;
+                const long long pix = (long long)y * p.Wo + x;
+                long long idx[16];
+                bool ok[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cg * COB + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    ok[r] = pok && co < p.Cout;
+                    idx[r] = ok[r] ? ((long long)n * p.Cout + co) * plane + pix : 0;
+                }
+                if (res) {   // block-uniform
+                    float rv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = res[idx[r]];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += rv[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (ok[r]) out[idx[r]] = v[r];
             }
         }
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // Small-Cout direct kernel (Cout <= 8: the SR tail conv F -> bands).  With 3..7 output channels an MFMA
