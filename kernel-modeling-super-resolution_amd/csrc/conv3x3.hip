@@ -78,7 +78,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Cin, int Co
 }
 
 template <int S, bool PS>
-__global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __restrict__ xg, const float* __restrict__ wpk,
+__global__ void __launch_bounds__(256, S == 1 ? 2 : 1) conv3x3_mfma_kernel(const float* __restrict__ xg, const float* __restrict__ wpk,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ res, float* __restrict__ out,
                                                               ConvParams p) {
@@ -450,7 +450,8 @@ extern "C" int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, 
                                     const float* bias, const float* residual, float* out, void* stream_) {
     if (!d) return fail(KMSR_E_BADARG, "null descriptor");
     if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return fail(KMSR_E_BADARG, "bad conv shape");
-    if (d->stride != 1) return fail(KMSR_E_UNSUPPORTED, "conv3x3 stride %d not implemented yet", d->stride);
+    if (d->stride != 1 && d->stride != 2) return fail(KMSR_E_UNSUPPORTED, "conv3x3 stride %d not supported (1 or 2)", d->stride);
+    if (d->stride == 2 && d->pixel_shuffle) return fail(KMSR_E_UNSUPPORTED, "pixel_shuffle needs stride 1");
     if (d->pixel_shuffle && (d->Cout % 4)) return fail(KMSR_E_SHAPE, "pixel_shuffle needs Cout %% 4 == 0 (Cout=%d)", d->Cout);
     if (d->pixel_shuffle && residual) return fail(KMSR_E_BADARG, "residual is not supported together with pixel_shuffle");
     if (!x || !packed_w || !out) return fail(KMSR_E_BADARG, "null tensor pointer");
@@ -461,6 +462,7 @@ extern "C" int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, 
     if ((long long)d->Cin * d->H * d->W >= (1ll << 31)) return fail(KMSR_E_UNSUPPORTED, "per-image input exceeds 2^31 elements");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (d->Cout <= kSmallCoMax) {
+        if (d->stride != 1) return fail(KMSR_E_UNSUPPORTED, "stride 2 with Cout <= %d is not implemented", kSmallCoMax);
         if (d->pixel_shuffle) return fail(KMSR_E_UNSUPPORTED, "pixel_shuffle with Cout <= %d is not implemented", kSmallCoMax);
         p.tiles_x = ceil_div(p.Wo, STW);
         p.tiles = p.tiles_x * ceil_div(p.Ho, STH);
@@ -485,6 +487,8 @@ extern "C" int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, 
     p.n_blocks = (int)nblocks;
     if (d->pixel_shuffle)
         conv3x3_mfma_kernel<1, true><<<p.n_blocks, 256, 0, stream>>>(x, packed_w, bias, residual, out, p);
+    else if (d->stride == 2)
+        conv3x3_mfma_kernel<2, false><<<p.n_blocks, 256, 0, stream>>>(x, packed_w, bias, residual, out, p);
     else
         conv3x3_mfma_kernel<1, false><<<p.n_blocks, 256, 0, stream>>>(x, packed_w, bias, residual, out, p);
     KMSR_HIP_CHECK(hipGetLastError());
