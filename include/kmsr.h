@@ -160,6 +160,23 @@ int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float
                          const float* residual,  /* out-shaped or NULL (not with pixel_shuffle)      */
                          float* out, void* stream);
 
+/* ============================================================================================
+ * KernelGAN kernel composition (BASELINE config 5: batched per-patch kernel estimation).
+ * Replaces the nested Python loops of
+ *   DynamicMultiBandLinearGenerator.extract_effective_kernels   muti_kernel/networks.py:135-202
+ *   MultiBandLinearGenerator.extract_effective_kernels          single_kernel/networks.py:108-157
+ * (about 20 000 tiny F.conv2d calls per sample there) by ONE launch, one workgroup per (sample, band):
+ *   K_0 = s_0 (.) W_0;  K_l[co] = sum_cm fullconv((s_l (.) W_l)[co,cm], K_{l-1}[cm])   (true 2-D convolution, :155-188)
+ *   k = mean over the last layer's output maps; k = max(k,0); k /= (sum(k) if sum(k) > 1e-12 else 1)   (:189-194)
+ * The chain has one input channel per band (ci[0] == 1), <= 8 layers, <= 64 channels, composed size <= 31.
+ *   weights  [C][sum_l co_l*ci_l*ks_l^2]  one band after the other, layers concatenated in order
+ *   scales   [B][C][sum_l co_l] per-output-channel scale factors (ConditionEncoder output) or NULL (= ones)
+ *   co, ci, ks  HOST int32 arrays [n_layers]
+ *   out      [B][C][K][K],  K = 1 + sum_l (ks_l - 1)
+ * ========================================================================================== */
+int kmsr_compose_kernels_f32(const float* weights, const float* scales, int32_t B, int32_t C, int32_t n_layers,
+                             const int32_t* co, const int32_t* ci, const int32_t* ks, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

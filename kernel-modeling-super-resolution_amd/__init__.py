@@ -8,9 +8,12 @@ from .degradation import (BAND_NAMES, add_noise, add_noise_batch, apply_kernel_d
                           build_noise_pool_from_arrays, degrade_batch, load_kernel, noise_crops, random_crop,
                           uses_fast_path, workspace_for)
 
+from .kernelgan import (ConditionEncoder, DynamicMultiBandLinearGenerator, MultiBandLinearGenerator,
+                        bulk_extract_kernels, compose_kernels)
 from .moe import ContentAdaptiveDegradation, NoiseEstimator, SelectorNet
 from .sr import SRNet, conv3x3, pack_conv3x3_weight, psnr
 
-__all__ = ["ContentAdaptiveDegradation", "NoiseEstimator", "SelectorNet", "SRNet", "conv3x3", "pack_conv3x3_weight", "psnr", "_lib", "BAND_NAMES", "add_noise", "add_noise_batch", "apply_kernel_degradation",
+__all__ = ["ConditionEncoder", "DynamicMultiBandLinearGenerator", "MultiBandLinearGenerator", "bulk_extract_kernels",
+           "compose_kernels", "ContentAdaptiveDegradation", "NoiseEstimator", "SelectorNet", "SRNet", "conv3x3", "pack_conv3x3_weight", "psnr", "_lib", "BAND_NAMES", "add_noise", "add_noise_batch", "apply_kernel_degradation",
            "build_noise_pool_from_arrays", "degrade_batch", "load_kernel", "noise_crops", "random_crop",
            "uses_fast_path", "workspace_for"]

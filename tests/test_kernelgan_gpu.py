@@ -1,0 +1,92 @@
+"""GPU parity of the KernelGAN kernel-composition path (BASELINE config 5) against golden vectors produced by the
+reference's own extract_effective_kernels (muti_kernel/networks.py:135-202, single_kernel/networks.py:108-157)."""
+import numpy as np
+import pytest
+import torch
+
+import kmsr_amd
+import oracle
+from conftest import assert_close, golden, landsat_like
+
+pytestmark = pytest.mark.gpu
+KG = golden("kernelgan.npz")
+
+
+def _sd(prefix):
+    return {k[len(prefix):]: torch.from_numpy(np.asarray(KG[k])) for k in KG.files if k.startswith(prefix)}
+
+
+def _muti():
+    g = kmsr_amd.DynamicMultiBandLinearGenerator(in_ch=5, mid_ch=32, ks=(7, 5, 3, 1, 1, 1), scale_gain=0.1)
+    sd = {k[len("generator."):]: v for k, v in _sd("muti_sd__").items() if k.startswith("generator.")}
+    g.load_state_dict(sd, strict=True)          # the reference's parameter names load unchanged
+    return g.cuda()
+
+
+def test_condition_encoder_scales(gpu_device):
+    g = _muti()
+    x = torch.from_numpy(KG["muti__x"]).cuda()
+    s = g.condition_encoder.scales_tensor(x)
+    assert_close(s.cpu().numpy(), KG["muti__scales"], rtol=5e-6, what="condition scales")
+    lst = g.condition_encoder(x)                 # reference return type: list[band][layer] of [B,out_c]
+    assert len(lst) == 5 and len(lst[0]) == 6 and tuple(lst[2][5].shape) == (2, 1) and tuple(lst[4][0].shape) == (2, 32)
+
+
+def test_muti_extract_effective_kernels(gpu_device):
+    g = _muti()
+    x = torch.from_numpy(KG["muti__x"]).cuda()
+    kb = g.extract_effective_kernels(x, reduce_batch=False)
+    assert tuple(kb.shape) == (2, 5, 13, 13)
+    assert_close(kb.cpu().numpy(), KG["muti__kernels_batch"], rtol=3e-4, atol=3e-7, what="batch kernels")
+    assert_close(g.extract_effective_kernels(x).cpu().numpy(), KG["muti__kernels_reduced"], rtol=3e-4, atol=3e-7, what="reduced")
+    assert_close(g.extract_effective_kernels(None).cpu().numpy(), KG["muti__kernels_noinput"], rtol=3e-4, atol=3e-7, what="no input")
+    assert_close(g.extract_merged_kernel(x).cpu().numpy(), KG["muti__kernels_reduced"].mean(0), rtol=3e-4, atol=3e-7, what="merged")
+    s = kb.sum(dim=(2, 3)).cpu().numpy()
+    assert np.allclose(s, 1.0, atol=1e-5) and float(kb.min()) >= 0.0      # invariant: non-negative, sums to 1
+
+
+def test_single_extract_effective_kernels(gpu_device):
+    g = kmsr_amd.MultiBandLinearGenerator(in_ch=5, mid_ch=32).cuda()
+    # default Gaussian init (single_kernel/networks.py:55-81): 7x7 Gaussian sigma=2 centred in 13x13
+    assert_close(g.extract_effective_kernels().cpu().numpy(), KG["single_default__kernels"], rtol=1e-5, atol=1e-9, what="default init")
+    g.load_state_dict(_sd("single_perturbed_sd__"), strict=True)
+    assert_close(g.extract_effective_kernels().cpu().numpy(), KG["single_perturbed__kernels"], rtol=3e-4, atol=3e-7, what="perturbed")
+
+
+def test_compose_against_oracle_other_shapes(gpu_device):
+    """Shapes the reference never uses (3 layers, 16 channels, 5/3/3 kernels) against the C oracle."""
+    rs = np.random.RandomState(0)
+    co, ci, ks = [16, 8, 2], [1, 16, 8], [5, 3, 3]
+    Ws = [[rs.randn(o, i, k, k).astype(np.float32) * 0.3 for o, i, k in zip(co, ci, ks)] for _ in range(3)]
+    sc = rs.rand(2, 3, sum(co)).astype(np.float32) + 0.5
+    flat = torch.from_numpy(np.stack([np.concatenate([w.reshape(-1) for w in band]) for band in Ws])).cuda()
+    got = kmsr_amd.compose_kernels(flat, torch.from_numpy(sc).cuda(), co, ci, ks).cpu().numpy()
+    for b in range(2):
+        for c in range(3):
+            off = np.cumsum([0] + co)
+            want = oracle.compose_kernel(Ws[c], [sc[b, c, off[l]:off[l + 1]] for l in range(3)])
+            assert_close(got[b, c], want, rtol=3e-4, atol=3e-7, what=f"compose b{b} c{c}")
+    with pytest.raises(AssertionError):        # channel chain mismatch -> KMSR_E_SHAPE
+        kmsr_amd.compose_kernels(flat, None, co, [1, 16, 7], ks)
+
+
+def test_bulk_extract_kernels_sharded(gpu_device):
+    """muti_kernel/train.py:118-188 at array level; rank sharding returns disjoint, complete, world-size-invariant results."""
+    g = _muti()
+    patches = [landsat_like((5, 72, 80), 100 + i) / 100.0 for i in range(5)]
+    full = dict(kmsr_amd.bulk_extract_kernels(patches, g, patch_size=64, batch_size=2))
+    assert sorted(full) == [0, 1, 2, 3, 4] and tuple(full[0].shape) == (5, 13, 13)
+    parts = {}
+    for r in range(2):
+        parts.update(dict(kmsr_amd.bulk_extract_kernels(patches, g, patch_size=64, batch_size=2, rank=r, world_size=2)))
+    assert sorted(parts) == sorted(full)
+    for i in full:
+        assert torch.allclose(parts[i], full[i], rtol=1e-6, atol=1e-9)
+    # centre crop (train.py:160-166) and agreement with the oracle on one patch
+    sd = {k: np.asarray(v) for k, v in KG.items() if k.startswith("muti_sd__")}
+    sd = {k[len("muti_sd__"):]: v for k, v in sd.items()}
+    crop = patches[3][:, 4:68, 8:72]
+    want = oracle.muti_extract_effective_kernels(sd, crop[None], reduce_batch=False)[0]
+    assert_close(full[3].cpu().numpy(), want, rtol=3e-4, atol=3e-7, what="bulk vs oracle")
+    with pytest.raises(ValueError):
+        kmsr_amd.bulk_extract_kernels([np.zeros((5, 32, 32), np.float32)], g, patch_size=64)
