@@ -222,18 +222,9 @@ def main():
     ap.add_argument("--workload", choices=["degrade_sr", "degrade"], default="degrade_sr")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
-    else:
-        dist = None
-        torch.cuda.set_device(0)
+    from kmsr_amd import dist as kd
+    rank, world, local = kd.init_from_env(backend="nccl")      # "nccl" is RCCL on ROCm; no group for a single process
+    torch.cuda.set_device(local if world > 1 else 0)
     device = torch.device("cuda", local if world > 1 else 0)
     L.require_gpu()
 
@@ -245,8 +236,7 @@ def main():
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    kd.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record()                       # on torch's current stream == the stream the kernels are launched on
@@ -254,16 +244,10 @@ def main():
         wl.step()
     ev1.record()
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    kd.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps      # one dominant kernel per step, back to back on one stream
-
-    if dist:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = kd.max_over_ranks(time.perf_counter() - t0, device=device)     # slowest rank defines the job's time
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
 
     if rank == 0:
         total_patches = wl.patches_per_step * args.steps * world
@@ -287,8 +271,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out), flush=True)
-    if dist:
-        dist.destroy_process_group()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

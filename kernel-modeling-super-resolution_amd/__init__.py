@@ -3,7 +3,7 @@
 The directory is named `kernel-modeling-super-resolution_amd`, which is not a valid Python identifier;
 `import kmsr_amd` (repo-root shim kmsr_amd.py) loads it under the name `kmsr_amd`.
 """
-from . import _lib
+from . import _lib, dist
 from .degradation import (BAND_NAMES, add_noise, add_noise_batch, apply_kernel_degradation,
                           build_noise_pool_from_arrays, degrade_batch, load_kernel, noise_crops, random_crop,
                           uses_fast_path, workspace_for)

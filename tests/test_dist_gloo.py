@@ -1,0 +1,88 @@
+"""world_size-2 gloo tests (CPU) of the multi-process plumbing used by bench.py --gpus N and by data-parallel training."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from kmsr_amd import dist as kd
+    r, w, _ = kd.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+    # (1) shards are disjoint and complete
+    mine = kd.shard_indices(11, r, w)
+    gathered = [None] * w
+    dist.all_gather_object(gathered, mine)
+    flat = sorted(i for g in gathered for i in g)
+    assert flat == list(range(11))
+    # (2) timing reductions
+    assert kd.max_over_ranks(1.0 + rank) == float(world)
+    assert kd.sum_over_ranks(1.0) == float(world)
+    # (3) data-parallel gradients: one flat bucket, mean over ranks == gradient of the mean loss over all samples
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 3, 3, padding=1))
+    if rank != 0:
+        for p_ in net.parameters():
+            p_.data.add_(1.0)                      # deliberately different start
+    kd.broadcast_parameters(net, src=0)
+    bucket = kd.GradBucket(net.parameters())
+    g = torch.Generator().manual_seed(42)
+    x_all, y_all = torch.randn(4, 3, 8, 8, generator=g), torch.randn(4, 3, 8, 8, generator=g)
+    sl = slice(rank * 2, rank * 2 + 2)            # 2 samples per rank
+    bucket.zero()
+    torch.nn.functional.mse_loss(net(x_all[sl]), y_all[sl]).backward()
+    work = bucket.all_reduce_mean(async_op=True)
+    bucket.finish(work)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 3, 3, padding=1))
+    ref.load_state_dict(net.state_dict())
+    torch.nn.functional.mse_loss(ref(x_all), y_all).backward()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-7)
+    # grads are views of the flat buffer (a single collective per step)
+    assert all(p_.grad.data_ptr() >= bucket.flat.data_ptr() for p_ in net.parameters())
+    kd.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, "ok"), (1, "ok")]
+
+
+def test_single_process_is_a_noop():
+    sys.path.insert(0, ROOT)
+    from kmsr_amd import dist as kd
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    assert kd.init_from_env() == (0, 1, 0)
+    assert kd.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert kd.max_over_ranks(3.5) == 3.5
+    b = kd.GradBucket(torch.nn.Linear(2, 2).parameters())
+    assert b.all_reduce_mean() is None
