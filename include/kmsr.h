@@ -177,6 +177,21 @@ int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float
 int kmsr_compose_kernels_f32(const float* weights, const float* scales, int32_t B, int32_t C, int32_t n_layers,
                              const int32_t* co, const int32_t* ci, const int32_t* ks, float* out, void* stream);
 
+/* ============================================================================================
+ * Backward of the 3x3 convolution (SR training step, SURVEY.md 8a S2 -- build-defined, stride 1).
+ *   data gradient  : dx = conv3x3(dy, w')  with w'[ci,co,u,v] = w[co,ci,2-u,2-v]  -> kmsr_conv3x3_fwd_f32 on weights
+ *                    packed with transpose_flip = 1 (Cin/Cout swapped in the descriptor).
+ *   weight gradient: dw[co,ci,u,v] = sum_{n,y,x} dy[n,co,y,x] * x[n,ci,y+u-1,x+v-1]      (zero padded x)
+ *                    fp32 MFMA, persistent workgroups accumulate 64x64x9 slabs in registers, partial slabs are
+ *                    written to the workspace and summed by a second kernel in a FIXED order (bit-reproducible,
+ *                    no float atomics).
+ *   bias gradient  : a plain reduction of dy; left to the caller (torch.sum).
+ * d describes the FORWARD conv (N,Cin,H,W,Cout; stride must be 1; relu/pixel_shuffle ignored).
+ * ========================================================================================== */
+size_t kmsr_conv3x3_wgrad_workspace_bytes(const kmsr_conv3x3_desc* d);
+int kmsr_conv3x3_wgrad_f32(const kmsr_conv3x3_desc* d, const float* x, const float* dy, float* dw /* [Cout,Cin,3,3] */,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

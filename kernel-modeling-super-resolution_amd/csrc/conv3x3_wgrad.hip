@@ -1,0 +1,207 @@
+// Weight gradient of the 3x3 convolution on the fp32 matrix cores (semantics: include/kmsr.h).
+//
+//   per tap t=(u,v):  dW_t[co, ci] += A[co, px] * B_t[px, ci],   A = dy,  B_t[px, ci] = x[ci, px shifted by (u-1, v-1)]
+//   one v_mfma_f32_32x32x2_f32 per 32 co x 32 ci x 2 pixels.  Lane l holds A[co = l&31][px = l>>5] and
+//   B[px = l>>5][ci = l&31], so both operands want channel-contiguous LDS images: tiles are staged TRANSPOSED
+//   ([pixel][channel], pitch 65 floats so that the transposing ds_writes are bank-conflict free).
+//
+// Persistent grid: every workgroup walks a strided list of pixel stages (2 rows x 32 cols of one image) and keeps a
+// whole 64 co x 64 ci x 9 tap slab in registers: wave w owns (co block w&1, ci block w>>1) = 9 accumulator tiles
+// (144 VGPRs).  The slab is written once to the workspace; reduce_partials_kernel sums the per-workgroup slabs in a
+// fixed order (deterministic, no float atomics).
+#include "kmsr_common.h"
+
+#include <algorithm>
+
+namespace kmsr {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int WR = 2, WC = 32;            // pixel stage: rows x cols
+constexpr int WPX = WR * WC;              // 64 pixels per stage
+constexpr int XR = WR + 2, XC = WC + 2;   // halo tile of x
+constexpr int XPOS = XR * XC;             // 136 positions
+constexpr int PCH = 65;                   // LDS pitch (floats) of one [pixel][64 channels] row
+constexpr int DYF = WPX * PCH;            // 4160
+constexpr int XF = XPOS * PCH;            // 8840
+constexpr int STAGE_F = DYF + XF;         // 13000 floats = 52 KB
+constexpr int NDY = WPX * 64 / 256;       // 16 loads / thread
+
+struct WgradParams {
+    int N, Cin, H, W, Cout;
+    int tiles_x, tiles_y, n_stages;       // stages per (image): tiles_y * tiles_x ; total = N * that
+    int cogs, cigs;                       // 64-channel groups
+    int nblk;                             // persistent workgroups per (co group, ci group)
+};
+
+__global__ void __launch_bounds__(256, 1) conv3x3_wgrad_kernel(const float* __restrict__ xg, const float* __restrict__ dyg,
+                                                               float* __restrict__ partial, WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE_F];
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wv & 1, ib = wv >> 1;
+    const int grp = blockIdx.y, cog = grp / p.cigs, cig = grp % p.cigs;
+    const int H = p.H, W = p.W;
+    const long long HW = (long long)H * W;
+    const int total = p.N * p.n_stages;
+
+    // ---- staging maps, computed once per thread (pixel / halo position fixed, channels stride per load):
+    //   dy : thread = (px = tid & 63, co_sub = tid >> 6)          -> 16 loads, co = 4q + co_sub
+    //   x  : thread = (pos = tid & 127, ci_sub = tid >> 7)        -> 32 loads, ci = 2q + ci_sub   (positions 0..127)
+    //        + 2 loads for the last 8 halo positions 128..135:       e = tid + 256 j -> pos = 128 + (e & 7), ci = e >> 3
+    const int dpx = tid & 63, dcs = tid >> 6, dr = dpx / WC, dc = dpx % WC;
+    const int xpos = tid & 127, xcs = tid >> 7, xrr = xpos / XC, xcc = xpos % XC;
+    int tpos[2], tci[2], trr[2], tcc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = tid + 256 * j;
+        tpos[j] = 128 + (e & 7); tci[j] = e >> 3; trr[j] = tpos[j] / XC; tcc[j] = tpos[j] % XC;
+    }
+    float dyr[NDY], xr[32], xt[2];
+    auto load_stage = [&](int s) {
+        const int n = s / p.n_stages, t = s % p.n_stages;
+        const int y0 = (t / p.tiles_x) * WR, x0 = (t % p.tiles_x) * WC;
+        const int co_left = p.Cout - cog * 64, ci_left = p.Cin - cig * 64;
+        const float* __restrict__ dyn = dyg + ((long long)n * p.Cout + cog * 64) * HW;
+        const float* __restrict__ xn = xg + ((long long)n * p.Cin + cig * 64) * HW;
+        {
+            const int y = y0 + dr, x = x0 + dc;
+            const bool pok = y < H && x < W;
+            const long long poff = pok ? (long long)y * W + x : 0;
+#pragma unroll
+            for (int q = 0; q < NDY; ++q) {
+                const int co = 4 * q + dcs;
+                const bool ok = pok && co < co_left;
+                const float v = dyn[ok ? co * HW + poff : 0];
+                dyr[q] = ok ? v : 0.f;
+            }
+        }
+        {
+            const int y = y0 - 1 + xrr, x = x0 - 1 + xcc;
+            const bool pok = y >= 0 && y < H && x >= 0 && x < W;
+            const long long poff = pok ? (long long)y * W + x : 0;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const int ci = 2 * q + xcs;
+                const bool ok = pok && ci < ci_left;
+                const float v = xn[ok ? ci * HW + poff : 0];
+                xr[q] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int yy = y0 - 1 + trr[j], xx = x0 - 1 + tcc[j];
+                const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W && tci[j] < ci_left;
+                const float v = xn[ok ? tci[j] * HW + (long long)yy * W + xx : 0];
+                xt[j] = ok ? v : 0.f;
+            }
+        }
+    };
+    auto store_stage = [&](int b) {
+        float* dl = lds + b * STAGE_F;
+        float* xl = dl + DYF;
+#pragma unroll
+        for (int q = 0; q < NDY; ++q) dl[dpx * PCH + 4 * q + dcs] = dyr[q];      // [px][co]
+#pragma unroll
+        for (int q = 0; q < 32; ++q) xl[xpos * PCH + 2 * q + xcs] = xr[q];       // [pos][ci]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xl[tpos[j] * PCH + tci[j]] = xt[j];
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    int s = blockIdx.x;
+    if (s < total) {
+        load_stage(s);
+        store_stage(0);
+    }
+    __syncthreads();
+    int b = 0;
+    for (; s < total; s += p.nblk) {
+        const bool more = s + p.nblk < total;
+        if (more) load_stage(s + p.nblk);                                       // in flight under the 288 MFMAs below
+        const float* dl = lds + b * STAGE_F;
+        const float* ap = dl + half * PCH + cb * 32 + l32;                      // + px*PCH
+        const float* bp = dl + DYF + half * PCH + ib * 32 + l32;                // + pos*PCH
+#pragma unroll
+        for (int r = 0; r < WR; ++r) {
+#pragma unroll 4
+            for (int c = 0; c < WC / 2; ++c) {
+                const float a = ap[(r * WC + 2 * c) * PCH];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float bv = bp[((r + t / 3) * XC + 2 * c + t % 3) * PCH];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        if (more) store_stage(b ^ 1);
+        __syncthreads();
+        b ^= 1;
+    }
+    // partial[(grp*nblk + blockIdx.x)][tap][co 64][ci 64]
+    float* out = partial + ((long long)grp * p.nblk + blockIdx.x) * (9 * 64 * 64);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            out[(t * 64 + co) * 64 + ib * 32 + l32] = acc[t][r];
+        }
+}
+
+// dw[co][ci][tap] = sum_blk partial[grp][blk][tap][co%64][ci%64]   (fixed order: deterministic)
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cin, int Cout,
+                                       int cigs, int nblk) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over Cout*Cin*9, ci fastest for coalesced partial reads
+    if (idx >= Cout * Cin * 9) return;
+    const int ci = idx % Cin, tap = (idx / Cin) % 9, co = idx / (Cin * 9);
+    const int grp = (co / 64) * cigs + ci / 64;
+    const float* src = partial + (long long)grp * nblk * (9 * 64 * 64) + (tap * 64 + co % 64) * 64 + ci % 64;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += src[(long long)b * (9 * 64 * 64)];
+    dw[((long long)co * Cin + ci) * 9 + tap] = s;
+}
+
+int wgrad_blocks(const kmsr_conv3x3_desc* d) {
+    const long long stages = (long long)d->N * ceil_div(d->H, WR) * ceil_div(d->W, WC);
+    return (int)std::min<long long>(stages, 256);   // one persistent workgroup per CU (52 KB x 2 LDS, 1 wave per SIMD)
+}
+
+}  // namespace
+}  // namespace kmsr
+
+using namespace kmsr;
+
+extern "C" size_t kmsr_conv3x3_wgrad_workspace_bytes(const kmsr_conv3x3_desc* d) {
+    if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return 0;
+    return (size_t)ceil_div(d->Cout, 64) * ceil_div(d->Cin, 64) * wgrad_blocks(d) * 9 * 64 * 64 * sizeof(float);
+}
+
+extern "C" int kmsr_conv3x3_wgrad_f32(const kmsr_conv3x3_desc* d, const float* x, const float* dy, float* dw,
+                                      void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!d) return fail(KMSR_E_BADARG, "null descriptor");
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return fail(KMSR_E_BADARG, "bad conv shape");
+    if (d->stride != 1) return fail(KMSR_E_UNSUPPORTED, "wgrad: stride %d not implemented", d->stride);
+    if (!x || !dy || !dw) return fail(KMSR_E_BADARG, "null tensor pointer");
+    const size_t need = kmsr_conv3x3_wgrad_workspace_bytes(d);
+    if (!workspace || workspace_bytes < need) return fail(KMSR_E_NOMEM, "wgrad workspace %zu B < required %zu B", workspace_bytes, need);
+    if ((long long)std::max(d->Cin, d->Cout) * d->H * d->W >= (1ll << 31)) return fail(KMSR_E_UNSUPPORTED, "per-image tensor exceeds 2^31 elements");
+    WgradParams p{};
+    p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
+    p.tiles_x = ceil_div(d->W, WC); p.tiles_y = ceil_div(d->H, WR); p.n_stages = p.tiles_x * p.tiles_y;
+    p.cogs = ceil_div(d->Cout, 64); p.cigs = ceil_div(d->Cin, 64);
+    p.nblk = wgrad_blocks(d);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    conv3x3_wgrad_kernel<<<dim3(p.nblk, p.cogs * p.cigs), 256, 0, stream>>>(x, dy, static_cast<float*>(workspace), p);
+    KMSR_HIP_CHECK(hipGetLastError());
+    const int total = d->Cout * d->Cin * 9;
+    reduce_partials_kernel<<<ceil_div(total, 256), 256, 0, stream>>>(static_cast<const float*>(workspace), dw, d->Cin,
+                                                                     d->Cout, p.cigs, p.nblk);
+    KMSR_HIP_CHECK(hipGetLastError());
+    return KMSR_OK;
+}

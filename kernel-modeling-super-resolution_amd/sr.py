@@ -64,6 +64,55 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     return out
 
 
+def conv3x3_wgrad(x, dy):
+    """dw[co,ci,u,v] = sum_{n,y,x} dy[n,co,y,x] * x[n,ci,y+u-1,x+v-1]  (stride 1, zero padding 1) -> [Cout,Cin,3,3]."""
+    lib = L.load()
+    x = x.contiguous()
+    dy = dy.contiguous()
+    assert x.is_cuda and dy.is_cuda and x.dtype == dy.dtype == torch.float32
+    N, Cin, H, W = x.shape
+    assert dy.shape[0] == N and tuple(dy.shape[2:]) == (H, W)
+    Cout = dy.shape[1]
+    d = L.Conv3x3Desc()
+    d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, Cin, H, W, Cout, 1
+    nbytes = lib.kmsr_conv3x3_wgrad_workspace_bytes(d)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    dw = torch.empty((Cout, Cin, 3, 3), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(lib.kmsr_conv3x3_wgrad_f32(d, L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(ws), nbytes, L.current_stream()))
+    return dw
+
+
+class Conv3x3Function(torch.autograd.Function):
+    """y = [relu](conv3x3(x, w) + b) with the HIP kernels in both directions (stride 1):
+    forward  kmsr_conv3x3_fwd_f32, backward  dx = conv3x3(g, flip-transposed w) (same kernel), dw = kmsr_conv3x3_wgrad_f32,
+    db = sum(g).  ReLU's mask is applied to the incoming gradient from the saved output."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x = x.contiguous()
+        y = conv3x3(x, pack_conv3x3_weight(weight), weight.shape[0], bias=bias, relu=relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.relu:
+            g = g * (y > 0)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv3x3(g, pack_conv3x3_weight(weight, transpose_flip=True), weight.shape[1])
+        if ctx.needs_input_grad[1]:
+            dw = conv3x3_wgrad(x, g)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g.sum(dim=(0, 2, 3))
+        return dx, dw, db, None
+
+
 class _PackCache:
     """Packed weights of one nn.Conv2d, rebuilt when the parameter is modified in place or replaced."""
 
@@ -111,11 +160,30 @@ class SRNet(nn.Module):
     def _conv(self, name, conv, x, **kw):
         return conv3x3(x, self._packed(name, conv), conv.out_channels, bias=conv.bias, **kw)
 
-    @torch.no_grad()
     def forward(self, x):
+        """Inference (torch.no_grad / eval): fully fused epilogues.  With grad enabled: the trainable path below."""
         L.require_gpu()
         if not x.is_cuda:
             raise L.KmsrError("SRNet.forward runs on the GPU only (no CPU fallback); move the input to cuda")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_train(x)
+        with torch.no_grad():
+            return self._forward_infer(x)
+
+    def _forward_train(self, x):
+        """Same network with autograd: every conv is Conv3x3Function (HIP forward, dgrad and wgrad); residual adds and
+        PixelShuffle are plain torch ops here (memory-bound permutations / adds, differentiable for free)."""
+        cv = lambda conv, t, relu=False: Conv3x3Function.apply(t, conv.weight, conv.bias, relu)
+        f = cv(self.head, x)
+        h = f
+        for blk in self.body:
+            h = h + cv(blk.conv2, cv(blk.conv1, h, True))
+        h = cv(self.body_tail, h) + f
+        for up in self.up:
+            h = torch.nn.functional.pixel_shuffle(cv(up, h), 2)
+        return cv(self.tail, h)
+
+    def _forward_infer(self, x):
         f = self._conv("head", self.head, x)
         h = f
         for i, blk in enumerate(self.body):
