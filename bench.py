@@ -213,13 +213,61 @@ class DegradeSRWorkload:
                           f"SRNetTorch fp32, {el:.1f} s on {cores} threads"}
 
 
+class TrainWorkload:
+    """BASELINE.json configs[2]: SR x4 TRAINING step with on-the-fly degradation from the 10-kernel pool, batch 32 per GPU,
+    data parallel: HR [32,5,1024,1024] --fused V-B degradation (random kernel of the bank per sample, Gaussian sigma)-->
+    LR [32,5,256,256] --SRNet fwd (HIP) --> L1 loss vs HR --> HIP dgrad/wgrad --> ONE flat-bucket gradient all-reduce
+    over RCCL --> Adam (betas of the reference's GAN trainers, muti_kernel/train.py:229)."""
+    name = "train_x4_lr256_c5_b32_ddp"
+
+    def __init__(self, device, rank, batch=32, C=5, h=256, w=256):
+        from kmsr_amd.sr import SRNet
+        from kmsr_amd import dist as kd
+        self.kd = kd
+        self.B, self.C, self.H, self.W = batch, C, 4 * h, 4 * w
+        self.hr = synth_hr(batch, C, self.H, self.W, device, seed=3000 + rank)
+        self.bank, self.sigma = moe_bank(device)
+        self.gen = torch.Generator().manual_seed(rank)
+        self.device = device
+        self.lr = torch.empty(batch, C, h, w, device=device)
+        self.ws = kmsr_amd.workspace_for(self.hr.shape, self.bank.shape, 4, "stride", device)
+        torch.manual_seed(0)
+        self.net = SRNet(C, 64, 16, 4).to(device)
+        kd.broadcast_parameters(self.net)
+        self.bucket = kd.GradBucket(self.net.parameters())
+        self.opt = torch.optim.Adam(self.net.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        self.step_no, self.taps_ready = 0, False
+        self.patches_per_step = batch
+        self.fwd_flops_per_patch = self.net.flops_per_lr_pixel() * h * w
+
+    def step(self):
+        kid = torch.randint(0, 10, (self.B,), generator=self.gen, dtype=torch.int32).to(self.device)
+        kmsr_amd.degrade_batch(self.hr, self.bank, 4, down="stride", pad="zero", normalize=False, kernel_idx=kid,
+                               sigma=self.sigma, noise="gaussian", seed=42, offset=self.step_no, out=self.lr,
+                               workspace=self.ws, taps_ready=self.taps_ready, flags=L.FLAG_FORCE_FAST)
+        self.taps_ready = True
+        self.step_no += 1
+        self.bucket.zero()
+        loss = torch.nn.functional.l1_loss(self.net(self.lr), self.hr)
+        loss.backward()
+        self.bucket.all_reduce_mean()
+        self.opt.step()
+        self.loss = loss
+
+    def roofline(self, step_ms):
+        tf = 3.0 * self.fwd_flops_per_patch * self.B / (step_ms * 1e-3) / 1e12      # fwd + dgrad + wgrad
+        return {"bound": "mfma", "kernel": "whole training step (fwd + dgrad + wgrad conv3x3 kernels)", "achieved": round(tf, 2),
+                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "algorithmic_flops_per_step": 3.0 * self.fwd_flops_per_patch * self.B, "step_ms": round(step_ms, 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["degrade_sr", "degrade"], default="degrade_sr")
+    ap.add_argument("--workload", choices=["degrade_sr", "degrade", "train"], default="degrade_sr")
     args = ap.parse_args()
 
     from kmsr_amd import dist as kd
@@ -228,7 +276,7 @@ def main():
     device = torch.device("cuda", local if world > 1 else 0)
     L.require_gpu()
 
-    wl = DegradeSRWorkload(device, rank) if args.workload == "degrade_sr" else DegradeWorkload(device, rank)
+    wl = {"degrade_sr": DegradeSRWorkload, "degrade": DegradeWorkload, "train": TrainWorkload}[args.workload](device, rank)
     for _ in range(max(args.warmup, 1)):
         wl.step()
     if hasattr(wl, "instrument"):
@@ -252,7 +300,8 @@ def main():
     if rank == 0:
         total_patches = wl.patches_per_step * args.steps * world
         out = {
-            "metric": "LR patches/sec (degrade+SR fwd) x4 256^2",
+            "metric": "LR patches/sec (degrade+SR fwd) x4 256^2" if args.workload != "train"
+            else "LR patches/sec (degrade + SR training step) x4 256^2",
             "value": round(total_patches / elapsed, 2),
             "unit": "LR patches/s",
             "n_gpus": world,
@@ -268,7 +317,7 @@ def main():
                        "sharding": f"independent patches, {wl.B}/GPU, no data-path collective"},
             "roofline": wl.roofline(kernel_ms),
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and hasattr(wl, "cpu_baseline"):
             out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
