@@ -232,7 +232,7 @@ class TrainWorkload:
         self.lr = torch.empty(batch, C, h, w, device=device)
         self.ws = kmsr_amd.workspace_for(self.hr.shape, self.bank.shape, 4, "stride", device)
         torch.manual_seed(0)
-        self.net = SRNet(C, 64, 16, 4).to(device)
+        self.net = SRNet(C, 64, 16, 4).to(device).train()
         kd.broadcast_parameters(self.net)
         self.bucket = kd.GradBucket(self.net.parameters())
         self.opt = torch.optim.Adam(self.net.parameters(), lr=1e-4, betas=(0.5, 0.999))

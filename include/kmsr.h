@@ -192,6 +192,20 @@ size_t kmsr_conv3x3_wgrad_workspace_bytes(const kmsr_conv3x3_desc* d);
 int kmsr_conv3x3_wgrad_f32(const kmsr_conv3x3_desc* d, const float* x, const float* dy, float* dw /* [Cout,Cin,3,3] */,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* ============================================================================================
+ * Winograd F(2x2,3x3) variant of the stride-1 forward convolution (same semantics and epilogues as
+ * kmsr_conv3x3_fwd_f32; exact fp32 arithmetic re-associated: Y = A^T[(G g G^T) .* (B^T d B)]A, 2.25x fewer MFMAs).
+ * The 16 transform-domain products are 16 independent [Cout x Cin] x [Cin x tiles] GEMMs on the fp32 matrix cores;
+ * each wave keeps all 16 accumulator tiles (256 AGPRs, one workgroup per CU) so the output transform is lane-local.
+ * Weights are consumed pre-transformed: packed layout [ceil(Cout/64)][ceil(Cin/8)][16][8][64] = G g G^T.
+ * Intended for Cin >= 16 and Cout >= 32 (the SR body / upsampler convs); numerically within ~1e-6 of the direct kernel.
+ * ========================================================================================== */
+size_t kmsr_conv3x3_wino_packed_weight_floats(int32_t Cin, int32_t Cout);
+int kmsr_conv3x3_wino_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int32_t Cin, int32_t Cout, float* packed,
+                                       void* stream);
+int kmsr_conv3x3_wino_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
+                              const float* residual, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

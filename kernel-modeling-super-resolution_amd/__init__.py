@@ -11,7 +11,7 @@ from .degradation import (BAND_NAMES, add_noise, add_noise_batch, apply_kernel_d
 from .kernelgan import (ConditionEncoder, DynamicMultiBandLinearGenerator, MultiBandLinearGenerator,
                         bulk_extract_kernels, compose_kernels)
 from .moe import ContentAdaptiveDegradation, NoiseEstimator, SelectorNet
-from .sr import SRNet, conv3x3, pack_conv3x3_weight, psnr
+from .sr import SRNet, conv3x3, pack_conv3x3_weight, pack_conv3x3_weight_wino, psnr
 
 __all__ = ["ConditionEncoder", "DynamicMultiBandLinearGenerator", "MultiBandLinearGenerator", "bulk_extract_kernels",
            "compose_kernels", "ContentAdaptiveDegradation", "NoiseEstimator", "SelectorNet", "SRNet", "conv3x3", "pack_conv3x3_weight", "psnr", "_lib", "BAND_NAMES", "add_noise", "add_noise_batch", "apply_kernel_degradation",

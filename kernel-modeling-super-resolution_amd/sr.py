@@ -33,8 +33,28 @@ def pack_conv3x3_weight(weight, transpose_flip=False):
     return packed
 
 
-def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuffle=False, stride=1, out=None):
-    """out = epilogue(conv3x3(x, w)) with zero padding 1 (semantics: include/kmsr.h).  x [N,Cin,H,W] float32 CUDA."""
+def pack_conv3x3_weight_wino(weight):
+    """[Cout,Cin,3,3] -> Winograd F(2x2,3x3) transformed + packed weights (G g G^T) for conv3x3(..., algo="winograd")."""
+    lib = L.load()
+    assert weight.is_cuda and weight.dtype == torch.float32 and weight.ndim == 4 and weight.shape[2:] == (3, 3)
+    w = weight.detach().contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    packed = torch.empty(lib.kmsr_conv3x3_wino_packed_weight_floats(Cin, Cout), device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        L.check(lib.kmsr_conv3x3_wino_pack_weights_f32(L.ptr(w), Cin, Cout, L.ptr(packed), L.current_stream()))
+    return packed
+
+
+def winograd_eligible(cin, cout, stride=1, width=2):
+    """Where the Winograd kernel applies/pays: stride 1, even width (patch rows are fetched as aligned float2) and
+    enough channels that the 64x16 chunk tiles are not mostly padding."""
+    return stride == 1 and width % 2 == 0 and cin >= 16 and cout >= 32
+
+
+def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuffle=False, stride=1, out=None,
+            algo="direct"):
+    """out = epilogue(conv3x3(x, w)) with zero padding 1 (semantics: include/kmsr.h).  x [N,Cin,H,W] float32 CUDA.
+    algo="direct": packed_w from pack_conv3x3_weight; algo="winograd": packed_w from pack_conv3x3_weight_wino."""
     lib = L.load()
     if not (x.is_cuda and x.dtype == torch.float32 and x.ndim == 4):
         raise ValueError("x must be a 4-D float32 CUDA tensor")
@@ -44,7 +64,10 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     d = L.Conv3x3Desc()
     d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, Cin, H, W, int(cout), int(stride)
     d.relu, d.pixel_shuffle = int(bool(relu)), int(bool(pixel_shuffle))
-    need = lib.kmsr_conv3x3_packed_weight_floats(Cin, int(cout))
+    wino = algo == "winograd"
+    if wino and stride != 1:
+        raise NotImplementedError("winograd conv needs stride 1")
+    need = (lib.kmsr_conv3x3_wino_packed_weight_floats if wino else lib.kmsr_conv3x3_packed_weight_floats)(Cin, int(cout))
     assert packed_w.is_cuda and packed_w.dtype == torch.float32 and packed_w.numel() == need, \
         f"packed weight has {packed_w.numel()} floats, conv {Cin}->{cout} needs {need}"
     oshape = (N, cout // 4, 2 * Ho, 2 * Wo) if pixel_shuffle else (N, cout, Ho, Wo)
@@ -59,8 +82,8 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
         residual = residual.contiguous()
         assert tuple(residual.shape) == oshape and residual.is_cuda
     with torch.cuda.device(x.device):
-        L.check(lib.kmsr_conv3x3_fwd_f32(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out),
-                                         L.current_stream()))
+        fwd = lib.kmsr_conv3x3_wino_fwd_f32 if wino else lib.kmsr_conv3x3_fwd_f32
+        L.check(fwd(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out), L.current_stream()))
     return out
 
 
@@ -120,11 +143,11 @@ class _PackCache:
         self.key = None
         self.packed = None
 
-    def get(self, conv):
+    def get(self, conv, wino=False):
         w = conv.weight
-        key = (w.data_ptr(), w._version, w.device)
+        key = (w.data_ptr(), w._version, w.device, wino)
         if key != self.key:
-            self.packed = pack_conv3x3_weight(w)
+            self.packed = pack_conv3x3_weight_wino(w) if wino else pack_conv3x3_weight(w)
             self.key = key
         return self.packed
 
@@ -150,22 +173,26 @@ class SRNet(nn.Module):
         self.up = nn.ModuleList([nn.Conv2d(n_feats, 4 * n_feats, 3, padding=1) for _ in range(int(math.log2(scale)))])
         self.tail = nn.Conv2d(n_feats, n_colors, 3, padding=1)
         self._caches = {}
+        self.use_winograd = True    # inference path: Winograd F(2x2,3x3) MFMA kernel for the F->F / F->4F convs
 
-    def _packed(self, name, conv):
+    def _packed(self, name, conv, wino=False):
         c = self._caches.get(name)
         if c is None:
             c = self._caches[name] = _PackCache()
-        return c.get(conv)
+        return c.get(conv, wino)
 
     def _conv(self, name, conv, x, **kw):
-        return conv3x3(x, self._packed(name, conv), conv.out_channels, bias=conv.bias, **kw)
+        wino = self.use_winograd and winograd_eligible(conv.in_channels, conv.out_channels, 1, x.shape[-1])
+        return conv3x3(x, self._packed(name, conv, wino), conv.out_channels, bias=conv.bias,
+                       algo="winograd" if wino else "direct", **kw)
 
     def forward(self, x):
-        """Inference (torch.no_grad / eval): fully fused epilogues.  With grad enabled: the trainable path below."""
+        """eval() mode or torch.no_grad(): the fused inference path.  train() mode with grad enabled (or an input that
+        requires grad): the autograd path below."""
         L.require_gpu()
         if not x.is_cuda:
             raise L.KmsrError("SRNet.forward runs on the GPU only (no CPU fallback); move the input to cuda")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and (self.training or x.requires_grad):
             return self._forward_train(x)
         with torch.no_grad():
             return self._forward_infer(x)

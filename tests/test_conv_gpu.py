@@ -68,11 +68,40 @@ def test_conv3x3_vs_torch(N, Cin, H, W, Cout, bias, relu, res, ps, gpu_device):
     _check(out, _ref_conv(x, w, b, relu, r, ps), what=f"conv {Cin}->{Cout} {H}x{W}")
 
 
+WINO_CASES = [
+    (2, 64, 40, 70, 64, True, True, False, False),      # ragged tiles (H % 4 != 0, W % 64 != 0)
+    (1, 64, 4, 64, 64, True, False, True, False),       # exactly one workgroup tile, residual
+    (1, 64, 24, 40, 256, True, False, False, True),     # upsampler: 4 cout groups + fused PixelShuffle
+    (2, 16, 33, 46, 32, False, True, True, False),      # smallest eligible channels, odd height, relu + residual
+    (1, 100, 9, 130, 70, True, False, False, False),    # Cin / Cout not multiples of 16 / 64
+    (1, 32, 1, 2, 32, True, True, False, True),         # 1x2 image + PixelShuffle
+]
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,bias,relu,res,ps", WINO_CASES)
+def test_conv3x3_winograd_vs_torch(N, Cin, H, W, Cout, bias, relu, res, ps, gpu_device):
+    """Winograd F(2x2,3x3) kernel: same semantics as the direct kernel, fp32 re-association only (~1e-6)."""
+    from kmsr_amd.sr import pack_conv3x3_weight_wino
+    g = torch.Generator().manual_seed(7 * N + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g) if bias else None
+    oshape = (N, Cout // 4, 2 * H, 2 * W) if ps else (N, Cout, H, W)
+    r = torch.randn(*oshape, generator=g) if res else None
+    out = conv3x3(x.cuda(), pack_conv3x3_weight_wino(w.cuda()), Cout, bias=None if b is None else b.cuda(), relu=relu,
+                  residual=None if r is None else r.cuda(), pixel_shuffle=ps, algo="winograd")
+    assert tuple(out.shape) == oshape
+    _check(out, _ref_conv(x, w, b, relu, r, ps), tol=2e-5, what=f"winograd {Cin}->{Cout} {H}x{W}")
+    direct = conv3x3(x.cuda(), pack_conv3x3_weight(w.cuda()), Cout, bias=None if b is None else b.cuda(), relu=relu,
+                     residual=None if r is None else r.cuda(), pixel_shuffle=ps)
+    _check(out, direct.double(), tol=2e-5, what="winograd vs direct")
+
+
 def test_conv3x3_tap_orientation_and_channel_map(gpu_device):
     """A = permutation check with asymmetric data: w[co,ci,u,v] = 1 iff ci == perm[co] and (u,v) == shift[co].
     Every output channel must equal ONE input channel shifted by one specific tap -- catches transposed taps
     (convolution vs cross-correlation), swapped row/col in the MFMA C layout and channel mix-ups, exactly."""
-    Cin, Cout, H, W = 24, 40, 19, 37
+    Cin, Cout, H, W = 24, 40, 19, 38
     g = torch.Generator().manual_seed(5)
     x = torch.randint(-8, 9, (2, Cin, H, W), generator=g).float()       # exact integer data
     perm = torch.randint(0, Cin, (Cout,), generator=g)
@@ -81,11 +110,15 @@ def test_conv3x3_tap_orientation_and_channel_map(gpu_device):
     for co in range(Cout):
         w[co, perm[co], taps[co] // 3, taps[co] % 3] = 1.0
     out = conv3x3(x.cuda(), pack_conv3x3_weight(w.cuda()), Cout).cpu()
+    from kmsr_amd.sr import pack_conv3x3_weight_wino
+    outw = conv3x3(x.cuda(), pack_conv3x3_weight_wino(w.cuda()), Cout, algo="winograd").cpu()
     xp = F.pad(x, (1, 1, 1, 1))
     for co in range(Cout):
         u, v = int(taps[co]) // 3, int(taps[co]) % 3
         want = xp[:, perm[co], u:u + H, v:v + W]
         assert torch.equal(out[:, co], want), f"channel {co}: tap ({u},{v}) of input {int(perm[co])}"
+        # integer data and 0/1 weights: the Winograd transforms are exact here too (halves of small integers)
+        assert torch.equal(outw[:, co], want), f"winograd channel {co}: tap ({u},{v}) of input {int(perm[co])}"
 
 
 def test_conv3x3_errors(gpu_device):

@@ -63,7 +63,7 @@ def test_srnet_training_step_matches_oracle(gpu_device):
     ref = SRNetTorch(3, 32, 2, 4)
     net = SRNet(3, 32, 2, 4)
     net.load_state_dict(ref.state_dict())
-    net = net.cuda()
+    net = net.cuda().train()
     g = torch.Generator().manual_seed(1)
     lr_img = torch.rand(2, 3, 24, 20, generator=g)
     hr_img = torch.rand(2, 3, 96, 80, generator=g)
