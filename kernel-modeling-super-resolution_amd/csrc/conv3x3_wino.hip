@@ -106,33 +106,38 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const float* __res
     constexpr int NP = WCK / 4;            // patches per thread per chunk
     constexpr int NU = UF / 4 / 256;       // float4 of U per thread per chunk
     f32x2 praw[NP][12];
+    bool pok[NP];
     f32x4 ureg[NU];
+    // The next chunk is fetched as 16 pieces (3 float2 of one patch row + one float4 of U each).
+    auto load_piece = [&](int chunk, int k) {       // k = 0..15 (compile-time after unrolling): patch j = k/4, row r = k%4
+        const int j = k >> 2, r = k & 3;
+        const int c = chunk * WCK + cs + 4 * j;
+        const bool okc = c < p.Cin;
+        const float* __restrict__ xc = xn + (long long)(okc ? c : 0) * HW;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = r * 3 + q;
+            // raw load from a clamped-safe address; the zero-padding / channel mask is applied at transform time so
+            // that nothing consumes the value (and waits for it) inside the MFMA phase
+            praw[j][e] = *reinterpret_cast<const f32x2*>(xc + (poff[e] >= 0 ? poff[e] : 0));
+        }
+        pok[j] = okc;
+        static_assert(NU == 16, "one U float4 per piece");
+        ureg[k] = reinterpret_cast<const f32x4*>(wcg + (long long)chunk * UF)[tid + 256 * k];
+    };
     auto load_chunk = [&](int chunk) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int c = chunk * WCK + cs + 4 * j;
-            const bool okc = c < p.Cin;
-            const float* __restrict__ xc = xn + (long long)(okc ? c : 0) * HW;
-#pragma unroll
-            for (int e = 0; e < 12; ++e) {
-                const bool in = poff[e] >= 0 && okc;
-                const f32x2 v = *reinterpret_cast<const f32x2*>(xc + (poff[e] >= 0 ? poff[e] : 0));   // safe address + select
-                praw[j][e] = in ? v : f32x2{0.f, 0.f};
-            }
-        }
-        const f32x4* __restrict__ wc = reinterpret_cast<const f32x4*>(wcg + (long long)chunk * UF);
-#pragma unroll
-        for (int t = 0; t < NU; ++t) ureg[t] = wc[tid + 256 * t];
+        for (int k = 0; k < 16; ++k) load_piece(chunk, k);
     };
     // V = B^T d B,  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
-    auto transform_store = [&](float* vb, const f32x2 (&pr)[12], int c) {
+    auto transform_store = [&](float* vb, const f32x2 (&pr)[12], bool okc, int c) {
         float d[16], t[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {            // columns c-1, c, c+1, c+2 out of the three aligned pairs
-            d[r * 4 + 0] = pr[r * 3 + 0].y;
-            d[r * 4 + 1] = pr[r * 3 + 1].x;
-            d[r * 4 + 2] = pr[r * 3 + 1].y;
-            d[r * 4 + 3] = pr[r * 3 + 2].x;
+        for (int r = 0; r < 4; ++r) {            // columns c-1, c, c+1, c+2 out of the three aligned pairs (+ padding mask)
+            d[r * 4 + 0] = (okc && poff[r * 3 + 0] >= 0) ? pr[r * 3 + 0].y : 0.f;
+            d[r * 4 + 1] = (okc && poff[r * 3 + 1] >= 0) ? pr[r * 3 + 1].x : 0.f;
+            d[r * 4 + 2] = (okc && poff[r * 3 + 1] >= 0) ? pr[r * 3 + 1].y : 0.f;
+            d[r * 4 + 3] = (okc && poff[r * 3 + 2] >= 0) ? pr[r * 3 + 2].x : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {            // rows: t = B^T d
@@ -155,7 +160,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const float* __res
 #pragma unroll
         for (int t = 0; t < NU; ++t) reinterpret_cast<f32x4*>(ub)[tid + 256 * t] = ureg[t];
 #pragma unroll
-        for (int j = 0; j < NP; ++j) transform_store(vb, praw[j], cs + 4 * j);
+        for (int j = 0; j < NP; ++j) transform_store(vb, praw[j], pok[j], cs + 4 * j);
     };
 
     f32x16 acc[16];
@@ -177,7 +182,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const float* __res
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
 #if KMSR_WINO_ABLATE != 1 && KMSR_WINO_ABLATE != 3
-            if (xi == 1 && more) load_chunk(chunk + 1);      // global loads issue in the MFMA shadow, ~3.5 us to land
+            if (xi == 1 && more) load_chunk(chunk + 1);      // one burst right after the first MFMAs: ~3.5 us to land
+                                                             // (spreading the pieces over the xi steps measured slower)
 #endif
 #pragma unroll
             for (int kp = 0; kp < WCK / 2; ++kp) {
