@@ -5,9 +5,10 @@
 //   M_xi[co, tile] = sum_ci U_xi[co,ci] * V_xi[ci,tile]       16 independent GEMMs -> v_mfma_f32_32x32x2_f32
 //   Y[co, tile]    = A^T M A           2x2 outputs per tile
 //
-// Workgroup = 4 waves = 64 output channels x 64 tiles (2 tile rows x 32 tile cols = 4 x 64 output pixels).  Wave w owns
-// (co block w&1, tile row w>>1) and ALL 16 xi: 16 accumulator tiles = 256 AGPRs (one workgroup per CU, one wave per
-// SIMD), so for every (co, tile) the 16 M values sit in ONE lane at one register index and A^T M A is lane-local.
+// Workgroup = 8 waves = 64 output channels x 64 tiles (2 tile rows x 32 tile cols = 4 x 64 output pixels), one workgroup
+// per CU, two waves per SIMD.  Wave = (co block, tile row, xi-row half): 8 accumulator tiles (128 AGPRs); for every
+// (co, tile) a wave's 8 M values sit in ONE lane at one register index, so its half of A^T M A is lane-local and the two
+// halves meet through a 64 KB LDS exchange (details at the kernel).
 // Input channels stream in chunks of 16: U chunk 16x16x64 and V chunk 16x16x64 floats (64 KB each) in ONE LDS stage.
 // A chunk's MFMA phase (128 MFMAs per wave, ~3.7 us) is long enough for the next chunk's raw 4x4 patches and U rows
 // (register staged, issued right after the first MFMAs) to land; they are transformed and written between two
@@ -66,15 +67,23 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, int Cin, int Cout,
     }
 }
 
+constexpr int kWinoThreads = 512;
+
 template <bool PS>
-__global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const float* __restrict__ xg, const float* __restrict__ wpk,
-                                                              const float* __restrict__ bias,
-                                                              const float* __restrict__ res, float* __restrict__ out,
-                                                              WinoParams p) {
+__global__ void __launch_bounds__(kWinoThreads, 2) conv3x3_wino_kernel(const float* __restrict__ xg,
+                                                                       const float* __restrict__ wpk,
+                                                                       const float* __restrict__ bias,
+                                                                       const float* __restrict__ res,
+                                                                       float* __restrict__ out, WinoParams p) {
+    // Workgroup = 8 waves, two per SIMD: wave = (co block cbk, tile row tb, xi-row half ih).  Wave (.,.,ih) multiplies the
+    // 8 transform points xi = 4 i + j with i in {2 ih, 2 ih + 1} (8 accumulator tiles = 128 AGPRs), so while one wave of a
+    // SIMD is stuck issuing its load burst or restaging, its partner keeps the matrix pipe busy.  Y = A^T (M A) is linear
+    // in the xi rows: the partners (wave, wave^4) exchange 2 partial sums per output through LDS and each finalises ONE
+    // of the tile's two output rows.
     __shared__ __attribute__((aligned(16))) float lds[WBUF];
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cbk = wv & 1, tb = wv >> 1;
+    const int cbk = wv & 1, tb = (wv >> 1) & 1, ih = wv >> 2;
 
     const int nb = p.n_blocks, bq = nb >> 3, br = nb & 7, xcd = blockIdx.x & 7;
     int bid = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (blockIdx.x >> 3);
@@ -86,13 +95,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const float* __res
     const int H = p.H, W = p.W;
     const long long HW = (long long)H * W;
 
-    // ---- input staging: thread = (tile t = tid & 63, channel sub-lane cs = tid >> 6); channels cs + 4j (j < 4) of the chunk
+    // ---- input staging: thread = (tile st = tid & 63, channel sub-lane cs = tid >> 6 in 0..7); channels cs, cs + 8 of the chunk
     const int st = tid & 63, cs = tid >> 6, str = st >> 5, stc = st & 31;
     // The 4x4 patch of tile (str, stc) covers rows ty0+2str-1 .. +2 and columns c-1 .. c+2 with c = tx0 + 2 stc (even).
     // Each row is fetched as three ALIGNED float2 (c-2,c-1) (c,c+1) (c+2,c+3): neighbouring lanes are exactly 8 bytes
-    // apart, so every load instruction is one contiguous 512-byte request (a dword gather with an 8-byte lane stride
-    // costs the texture-address path twice as many instructions at half the efficiency).  W is even on this path, so
-    // an aligned pair is entirely inside or entirely outside the image.
+    // apart, so every load instruction is one contiguous 512-byte request.  W is even on this path, so an aligned pair
+    // is entirely inside or entirely outside the image.
     const int py0 = ty0 + 2 * str - 1, pc0 = tx0 + 2 * stc - 2;
     int poff[12];       // [row r][pair k]: offset of the pair inside one channel plane, -1 = outside (zero padding)
 #pragma unroll
@@ -103,31 +111,25 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const float* __res
     const float* __restrict__ xn = xg + (long long)n * p.Cin * HW;
     const float* __restrict__ wcg = wpk + (long long)cg * p.nchunks * UF;
 
-    constexpr int NP = WCK / 4;            // patches per thread per chunk
-    constexpr int NU = UF / 4 / 256;       // float4 of U per thread per chunk
+    constexpr int NP = WCK / 8;                       // patches per thread per chunk (2)
+    constexpr int NU = UF / 4 / kWinoThreads;         // float4 of U per thread per chunk (8)
     f32x2 praw[NP][12];
     bool pok[NP];
     f32x4 ureg[NU];
-    // The next chunk is fetched as 16 pieces (3 float2 of one patch row + one float4 of U each).
-    auto load_piece = [&](int chunk, int k) {       // k = 0..15 (compile-time after unrolling): patch j = k/4, row r = k%4
-        const int j = k >> 2, r = k & 3;
-        const int c = chunk * WCK + cs + 4 * j;
-        const bool okc = c < p.Cin;
-        const float* __restrict__ xc = xn + (long long)(okc ? c : 0) * HW;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int e = r * 3 + q;
-            // raw load from a clamped-safe address; the zero-padding / channel mask is applied at transform time so
-            // that nothing consumes the value (and waits for it) inside the MFMA phase
-            praw[j][e] = *reinterpret_cast<const f32x2*>(xc + (poff[e] >= 0 ? poff[e] : 0));
-        }
-        pok[j] = okc;
-        static_assert(NU == 16, "one U float4 per piece");
-        ureg[k] = reinterpret_cast<const f32x4*>(wcg + (long long)chunk * UF)[tid + 256 * k];
-    };
     auto load_chunk = [&](int chunk) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) load_piece(chunk, k);
+        for (int j = 0; j < NP; ++j) {
+            const int c = chunk * WCK + cs + 8 * j;
+            const bool okc = c < p.Cin;
+            const float* __restrict__ xc = xn + (long long)(okc ? c : 0) * HW;
+#pragma unroll
+            for (int e = 0; e < 12; ++e)   // raw loads from clamped-safe addresses; the padding mask is applied at transform time
+                praw[j][e] = *reinterpret_cast<const f32x2*>(xc + (poff[e] >= 0 ? poff[e] : 0));
+            pok[j] = okc;
+        }
+        const f32x4* __restrict__ wc = reinterpret_cast<const f32x4*>(wcg + (long long)chunk * UF);
+#pragma unroll
+        for (int t = 0; t < NU; ++t) ureg[t] = wc[tid + kWinoThreads * t];
     };
     // V = B^T d B,  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
     auto transform_store = [&](float* vb, const f32x2 (&pr)[12], bool okc, int c) {
@@ -158,19 +160,19 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const float* __res
         float* ub = lds;
         float* vb = ub + UF;
 #pragma unroll
-        for (int t = 0; t < NU; ++t) reinterpret_cast<f32x4*>(ub)[tid + 256 * t] = ureg[t];
+        for (int t = 0; t < NU; ++t) reinterpret_cast<f32x4*>(ub)[tid + kWinoThreads * t] = ureg[t];
 #pragma unroll
-        for (int j = 0; j < NP; ++j) transform_store(vb, praw[j], pok[j], cs + 4 * j);
+        for (int j = 0; j < NP; ++j) transform_store(vb, praw[j], pok[j], cs + 8 * j);
     };
 
-    f32x16 acc[16];
+    f32x16 acc[8];      // local index il*4 + j  <->  xi = (2 ih + il)*4 + j
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-    const int aoff = half * WCO + cbk * 32 + l32;     // + (xi*WCK + 2*kp) * WCO
-    const int boff = half * NT + tb * 32 + l32;       // + (xi*WCK + 2*kp) * NT
+    const int aoff = half * WCO + cbk * 32 + l32 + (8 * ih) * WCK * WCO;     // + (a*WCK + 2*kp) * WCO
+    const int boff = half * NT + tb * 32 + l32 + (8 * ih) * WCK * NT;        // + (a*WCK + 2*kp) * NT
     const float* ub = lds;
     const float* vb = lds + UF;
 
@@ -180,19 +182,18 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const float* __res
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const bool more = chunk + 1 < p.nchunks;     // block-uniform
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
+        for (int a = 0; a < 8; ++a) {
 #if KMSR_WINO_ABLATE != 1 && KMSR_WINO_ABLATE != 3
-            if (xi == 1 && more) load_chunk(chunk + 1);      // one burst right after the first MFMAs: ~3.5 us to land
-                                                             // (spreading the pieces over the xi steps measured slower)
+            if (a == 1 && more) load_chunk(chunk + 1);       // one burst right after the first MFMAs: ~3.5 us to land
 #endif
 #pragma unroll
             for (int kp = 0; kp < WCK / 2; ++kp) {
-                const float a = ub[aoff + (xi * WCK + 2 * kp) * WCO];
-                const float bv = vb[boff + (xi * WCK + 2 * kp) * NT];
+                const float av = ub[aoff + (a * WCK + 2 * kp) * WCO];
+                const float bv = vb[boff + (a * WCK + 2 * kp) * NT];
 #if KMSR_WINO_ABLATE == 2
-                asm volatile("" ::"v"(a), "v"(bv));
+                asm volatile("" ::"v"(av), "v"(bv));
 #else
-                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[xi], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
 #endif
             }
         }
@@ -205,89 +206,79 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const float* __res
         }
     }
 
-    // ---- epilogue: lane-local output transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]), bias, ReLU, residual, store
-    float* sbias = lds;
+    // ---- epilogue.  Own half of the column transform: MA[il][b], il = 0,1 (xi rows 2ih, 2ih+1), b = 0,1 (A^T = [[1,1,1,0],[0,1,-1,-1]]).
+    //      Row transform: Y[0][b] = MA_0 + MA_1 + MA_2,  Y[1][b] = MA_1 - MA_2 - MA_3  -> per wave a "keep" part for the
+    //      output row it finalises (row ih) and a "send" part for the partner's row.
+    f32x2* xch = reinterpret_cast<f32x2*>(lds);              // [8 waves][16 regs][64 lanes] float2 = 64 KB (U/V are dead)
+    float* sbias = lds + 8 * 16 * 64 * 2;
     if (tid < WCO) {
         const int co = cg * WCO + tid;
         sbias[tid] = (bias && co < p.Cout) ? bias[co] : 0.f;
     }
+    f32x2 keep[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        float ma[2][2];
+#pragma unroll
+        for (int il = 0; il < 2; ++il) {
+            const float m0 = acc[il * 4 + 0][reg], m1 = acc[il * 4 + 1][reg], m2 = acc[il * 4 + 2][reg], m3 = acc[il * 4 + 3][reg];
+            ma[il][0] = m0 + m1 + m2;
+            ma[il][1] = m1 - m2 - m3;
+        }
+        f32x2 send;
+        if (ih == 0) {      // xi rows 0,1: Y0 += MA_0 + MA_1 (keep), Y1 += MA_1 (send)
+            keep[reg] = f32x2{ma[0][0] + ma[1][0], ma[0][1] + ma[1][1]};
+            send = f32x2{ma[1][0], ma[1][1]};
+        } else {            // xi rows 2,3: Y0 += MA_2 (send), Y1 += -MA_2 - MA_3 (keep)
+            keep[reg] = f32x2{-ma[0][0] - ma[1][0], -ma[0][1] - ma[1][1]};
+            send = f32x2{ma[0][0], ma[0][1]};
+        }
+        xch[(wv * 16 + reg) * 64 + lane] = send;
+    }
     __syncthreads();
 #if KMSR_WINO_ABLATE == 4
-    if (p.relu != 12345) { if (tid == 0 && acc[0][0] == 1.2345f) out[0] = acc[3][2]; return; }
+    if (p.relu != 12345) { if (tid == 0 && keep[0].x == 1.2345f) out[0] = keep[3].y; return; }
 #endif
-    const int y0 = ty0 + 2 * tb, x0 = tx0 + 2 * l32;          // top-left output pixel of this lane's tile
-    const bool row0 = y0 < H, row1 = y0 + 1 < H, col0 = x0 < W, col1 = x0 + 1 < W;
+    const int y = ty0 + 2 * tb + ih, x0 = tx0 + 2 * l32;     // this wave finalises output row `ih` of its tiles
+    const bool pok2 = y < H && x0 < W;                        // (x0, x0+1) is an aligned pair: inside or outside as a whole
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int co0 = cg * WCO + cbk * 32 + 8 * g + 4 * half;              // channels co0 .. co0+3 <-> registers 4g .. 4g+3
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + cbk * 32 + 8 * g + 4 * half);
         const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-        float Y[4][4];                                                       // [channel r][2*a + b]
+        f32x2 Y[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int reg = 4 * g + r;
-            float s0[4], s1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float m0 = acc[0 * 4 + j][reg], m1 = acc[1 * 4 + j][reg], m2 = acc[2 * 4 + j][reg], m3 = acc[3 * 4 + j][reg];
-                s0[j] = m0 + m1 + m2;
-                s1[j] = m1 - m2 - m3;
-            }
-            Y[r][0] = s0[0] + s0[1] + s0[2] + bb[r];
-            Y[r][1] = s0[1] - s0[2] - s0[3] + bb[r];
-            Y[r][2] = s1[0] + s1[1] + s1[2] + bb[r];
-            Y[r][3] = s1[1] - s1[2] - s1[3] + bb[r];
-            if (p.relu) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) Y[r][q] = fmaxf(Y[r][q], 0.f);
-            }
+            const f32x2 o = xch[((wv ^ 4) * 16 + 4 * g + r) * 64 + lane];
+            Y[r] = f32x2{keep[4 * g + r].x + o.x + bb[r], keep[4 * g + r].y + o.y + bb[r]};
+            if (p.relu) Y[r] = f32x2{fmaxf(Y[r].x, 0.f), fmaxf(Y[r].y, 0.f)};
         }
         if constexpr (PS) {
-            // conv channel q = co0 + r -> out[n, q>>2, 2y + (r>>1), 2x + (r&1)]: the lane owns a 4x4 output block
-            if (co0 < p.Cout && col0) {
+            // conv channel q = co0 + r -> out[n, q>>2, 2y + (r>>1), 2x + (r&1)]: this lane writes rows 2y, 2y+1, cols 2x0 .. 2x0+3
+            if (pok2 && co0 < p.Cout) {
                 const long long W2 = 2ll * W;
-                float* o = out + (((long long)n * (p.Cout >> 2) + (co0 >> 2)) * (2ll * H) + 2 * y0) * W2 + 2 * x0;
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {            // output pixel row y0 + a
-                    if (a == 0 ? !row0 : !row1) continue;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {        // sub-row i of the shuffle
-                        float* orow = o + (2 * a + i) * W2;
-                        const f32x2 left = {Y[2 * i + 0][2 * a + 0], Y[2 * i + 1][2 * a + 0]};      // pixel x0
-                        const f32x2 right = {Y[2 * i + 0][2 * a + 1], Y[2 * i + 1][2 * a + 1]};     // pixel x0 + 1
-                        *reinterpret_cast<f32x2*>(orow) = left;
-                        if (col1) *reinterpret_cast<f32x2*>(orow + 2) = right;
-                    }
-                }
+                float* o = out + (((long long)n * (p.Cout >> 2) + (co0 >> 2)) * (2ll * H) + 2 * y) * W2 + 2 * x0;
+                *reinterpret_cast<f32x4*>(o) = f32x4{Y[0].x, Y[1].x, Y[0].y, Y[1].y};
+                *reinterpret_cast<f32x4*>(o + W2) = f32x4{Y[2].x, Y[3].x, Y[2].y, Y[3].y};
             }
         } else {
-            // W is even and x0 is even: (x0, x0+1) is an aligned pair that is inside or outside the image as a whole, so
-            // every row of the lane's 2x2 block is ONE 8-byte access and a wave's store is a contiguous 512-byte row piece
             const long long plane = (long long)H * W;
-            const long long base = ((long long)n * p.Cout + co0) * plane + (long long)y0 * W + x0;
-            f32x2 r0[4], r1[4];
+            const long long base = ((long long)n * p.Cout + co0) * plane + (long long)y * W + x0;
+            f32x2 rr[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                r0[r] = f32x2{0.f, 0.f};
-                r1[r] = f32x2{0.f, 0.f};
-            }
-            if (res) {   // block-uniform; all loads issued before any is consumed, from clamped-safe addresses
+            for (int r = 0; r < 4; ++r) rr[r] = f32x2{0.f, 0.f};
+            if (res) {   // block-uniform; loads issued together from clamped-safe addresses
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool okc = co0 + r < p.Cout && col0;
-                    const f32x2 a0 = *reinterpret_cast<const f32x2*>(res + ((okc && row0) ? base + r * plane : 0));
-                    const f32x2 a1 = *reinterpret_cast<const f32x2*>(res + ((okc && row1) ? base + r * plane + W : 0));
-                    r0[r] = (okc && row0) ? a0 : f32x2{0.f, 0.f};
-                    r1[r] = (okc && row1) ? a1 : f32x2{0.f, 0.f};
+                    const bool ok = pok2 && co0 + r < p.Cout;
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(res + (ok ? base + r * plane : 0));
+                    rr[r] = ok ? v : f32x2{0.f, 0.f};
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (co0 + r >= p.Cout || !col0) continue;
-                float* o = out + base + r * plane;
-                if (row0) *reinterpret_cast<f32x2*>(o) = f32x2{Y[r][0] + r0[r].x, Y[r][1] + r0[r].y};
-                if (row1) *reinterpret_cast<f32x2*>(o + W) = f32x2{Y[r][2] + r1[r].x, Y[r][3] + r1[r].y};
-            }
+            for (int r = 0; r < 4; ++r)
+                if (pok2 && co0 + r < p.Cout)
+                    *reinterpret_cast<f32x2*>(out + base + r * plane) = f32x2{Y[r].x + rr[r].x, Y[r].y + rr[r].y};
         }
     }
 }
@@ -336,9 +327,9 @@ extern "C" int kmsr_conv3x3_wino_fwd_f32(const kmsr_conv3x3_desc* d, const float
     p.n_blocks = (int)nblocks;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (d->pixel_shuffle)
-        conv3x3_wino_kernel<true><<<p.n_blocks, 256, 0, stream>>>(x, packed_w, bias, residual, out, p);
+        conv3x3_wino_kernel<true><<<p.n_blocks, kWinoThreads, 0, stream>>>(x, packed_w, bias, residual, out, p);
     else
-        conv3x3_wino_kernel<false><<<p.n_blocks, 256, 0, stream>>>(x, packed_w, bias, residual, out, p);
+        conv3x3_wino_kernel<false><<<p.n_blocks, kWinoThreads, 0, stream>>>(x, packed_w, bias, residual, out, p);
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
 }
