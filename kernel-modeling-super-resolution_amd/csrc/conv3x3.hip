@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256) conv3x3_smallco_kernel(const float* __res
         if (chunk + 1 < nchunks) load_chunk(chunk + 1);
         const float* inb = lds + b * IN_FLOATS + ty * SIWP + 4 * tx;
         const float* __restrict__ wc = wpk + (long long)chunk * SCK * 9 * COUT;   // wave-uniform
-#pragma unroll
+#pragma unroll 1   // keep one channel's 18 LDS values live at a time: ~100 VGPRs -> 4 waves/SIMD instead of 2
         for (int c = 0; c < SCK; ++c) {
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
