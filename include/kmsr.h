@@ -206,6 +206,18 @@ int kmsr_conv3x3_wino_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int3
 int kmsr_conv3x3_wino_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
                               const float* residual, float* out, void* stream);
 
+/* ============================================================================================
+ * Small-channel convolution with REFLECT padding and per-unit weights -- the KernelGAN generators' forward
+ * (DynamicMultiBandLinearGenerator._apply_conv_chain  muti_kernel/networks.py:101-117,
+ *  MultiBandLinearGenerator.forward                    single_kernel/networks.py:83-106):
+ * every (sample, band) "unit" runs its own bias-free chain of k x k convs with F.pad(mode='reflect') per layer.
+ *   out[u,co,y,x] = sum_{ci,a,b} w[u,ci,a*k+b,co] * x[u,ci,refl(y+a-k/2),refl(x+b-k/2)],  refl(-i) = i, refl(H-1+i) = H-1-i
+ *   x [U,Cin,H,W], w [U][Cin][k*k][Cout] (already scaled / folded by the caller), out [U,Cout,H,W]
+ *   k in {1,3,5,7}, Cin <= 32, Cout in {1, 32}; H, W > k/2.
+ * ========================================================================================== */
+int kmsr_conv_reflect_f32(const float* x, const float* w, int32_t U, int32_t Cin, int32_t Cout, int32_t H, int32_t W,
+                          int32_t k, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

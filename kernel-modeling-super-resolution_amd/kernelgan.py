@@ -7,8 +7,10 @@ Mirrors, with identical class names, constructor arguments and parameter names (
     bulk_extract_kernels                   muti_kernel/train.py:118-188     (array-level: patches in, kernels out)
 
 extract_effective_kernels is ONE launch of kmsr_compose_kernels_f32 (one workgroup per (sample, band)) instead of
-~20 000 tiny F.conv2d calls per sample.  The generators' forward (reflect-padded 6-layer chain, used only by the
-GAN trainer) is SURVEY 8f N1 "next" and is not implemented here; calling it raises.
+~20 000 tiny F.conv2d calls per sample.  The generators' forward (reflect-padded 6-layer chain + 3 avg-pools) runs as
+three launches of kmsr_conv_reflect_f32 over all (sample, band) units: the three trailing 1x1 layers carry no padding,
+so they fold exactly into the 3x3 layer (7x7 1->32, 5x5 32->32, 3x3 32->1).  Inference-only (the GAN trainers that
+would need its backward are SURVEY 8f N1 "next").
 """
 import ctypes as C
 from typing import Optional, Sequence
@@ -21,6 +23,49 @@ from . import _lib as L
 from .sr import conv3x3, pack_conv3x3_weight
 
 KS = (7, 5, 3, 1, 1, 1)
+
+
+def conv_reflect(x, w, k, cout):
+    """x [U,Cin,H,W], w [U,Cin,k*k,Cout] (per-unit weights) -> [U,Cout,H,W]; reflect padding k//2 (include/kmsr.h)."""
+    lib = L.load()
+    x = x.contiguous()
+    w = w.contiguous()
+    U, Cin, H, W = x.shape
+    assert w.shape == (U, Cin, k * k, cout), f"weights {tuple(w.shape)} != {(U, Cin, k * k, cout)}"
+    out = torch.empty((U, cout, H, W), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(lib.kmsr_conv_reflect_f32(L.ptr(x), L.ptr(w), U, Cin, cout, H, W, k, L.ptr(out), L.current_stream()))
+    return out
+
+
+def _chain_forward(x, W, scales):
+    """x [B,C,H,W]; W: list over bands of the 6 layer weights [co,ci,k,k]; scales [B,C,161] or None.
+    Returns [B,C,H/8,W/8] (muti_kernel/networks.py:101-133, single_kernel/networks.py:83-106)."""
+    B, Cc, H, Wd = x.shape
+    dev = x.device
+    w = [torch.stack([band[l].detach() for band in W]).to(dev) for l in range(6)]      # [C,co,ci,k,k] per layer
+    offs = [0, 32, 64, 96, 128, 160, 161]
+    if scales is None:
+        s = [torch.ones(B, Cc, offs[l + 1] - offs[l], device=dev) for l in range(6)]
+    else:
+        s = [scales[:, :, offs[l]:offs[l + 1]] for l in range(6)]                       # [B,C,co_l]
+    U = B * Cc
+    # layer 1: [U, ci=1, 49, 32]
+    w1 = torch.einsum('ckt,bck->bctk', w[0].reshape(Cc, 32, 49), s[0]).reshape(U, 1, 49, 32)
+    # layer 2: [U, 32, 25, 32]
+    w2 = torch.einsum('ckit,bck->bcitk', w[1].reshape(Cc, 32, 32, 25), s[1]).reshape(U, 32, 25, 32)
+    # layers 4..6 (1x1, no padding) fold into layer 3:  v = (s6 W6)(s5 W5)(s4 W4)  ->  w3'[ci,tap] = sum_co v[co] s3[co] W3[co,ci,tap]
+    m4 = torch.einsum('coi,bco->bcoi', w[3].reshape(Cc, 32, 32), s[3])
+    m5 = torch.einsum('coi,bco->bcoi', w[4].reshape(Cc, 32, 32), s[4])
+    m6 = torch.einsum('coi,bco->bcoi', w[5].reshape(Cc, 1, 32), s[5])
+    v = torch.matmul(torch.matmul(m6, m5), m4).reshape(B, Cc, 32) * s[2]                # [B,C,32] over layer-3 outputs
+    w3 = torch.einsum('bck,ckit->bcit', v, w[2].reshape(Cc, 32, 32, 9)).reshape(U, 32, 9, 1)
+    h = conv_reflect(x.reshape(U, 1, H, Wd), w1, 7, 32)
+    h = conv_reflect(h, w2, 5, 32)
+    h = conv_reflect(h, w3, 3, 1)
+    for _ in range(3):                                                                   # down1..down3 (:114-116)
+        h = torch.nn.functional.avg_pool2d(h, kernel_size=2, stride=2)
+    return h.reshape(B, Cc, H // 8, Wd // 8)
 
 
 def compose_kernels(weights, scales, co, ci, ks):
@@ -118,9 +163,11 @@ class DynamicMultiBandLinearGenerator(nn.Module):
     def _flat_weights(self):
         return torch.stack([torch.cat([w.detach().reshape(-1) for w in band]) for band in self.weight_bands])
 
+    @torch.no_grad()
     def forward(self, x):
-        raise NotImplementedError("generator forward (GAN training path) is SURVEY 8f N1 'next'; "
-                                  "use extract_effective_kernels for kernel estimation")
+        """:119-133 -- [B,C,H,W] -> [B,C,H/8,W/8]; per-sample, per-band chains with condition-encoder scales."""
+        L.require_gpu()
+        return _chain_forward(x, [list(band) for band in self.weight_bands], self.condition_encoder.scales_tensor(x))
 
     @torch.no_grad()
     def extract_effective_kernels(self, x: Optional[torch.Tensor] = None, reduce_batch: bool = True) -> torch.Tensor:
@@ -173,8 +220,11 @@ class MultiBandLinearGenerator(nn.Module):
             convs[-1].weight.zero_()
             convs[-1].weight.fill_(1.0 / self.mid_ch)
 
+    @torch.no_grad()
     def forward(self, x):
-        raise NotImplementedError("generator forward (GAN training path) is SURVEY 8f N1 'next'")
+        """single_kernel/networks.py:83-106 -- [B,C,H,W] -> [B,C,H/8,W/8]."""
+        L.require_gpu()
+        return _chain_forward(x, [[c.weight for c in convs] for convs in self.chains], None)
 
     @torch.no_grad()
     def extract_effective_kernels(self) -> torch.Tensor:
@@ -187,6 +237,24 @@ class MultiBandLinearGenerator(nn.Module):
     @torch.no_grad()
     def extract_merged_kernel(self) -> torch.Tensor:
         return self.extract_effective_kernels().mean(dim=0)
+
+
+class DegradationModel(nn.Module):
+    """muti_kernel/networks.py:227-247: dynamic blur generator + learnable per-band Gaussian noise;
+    forward(x) -> (clean, noisy, sigma).  state_dict keys `generator.*`, `noise_estimator.log_sigma` as in the reference."""
+
+    def __init__(self, in_ch: int = 5, mid_ch: int = 32, ks: Sequence[int] = KS, scale_gain: float = 0.1,
+                 noise_init: float = 0.01, noise_max: float = 0.2) -> None:
+        super().__init__()
+        from .moe import NoiseEstimator
+        self.generator = DynamicMultiBandLinearGenerator(in_ch=in_ch, mid_ch=mid_ch, ks=ks, scale_gain=scale_gain)
+        self.noise_estimator = NoiseEstimator(channels=in_ch, init_sigma=noise_init, sigma_max=noise_max)
+
+    @torch.no_grad()
+    def forward(self, x):
+        clean = self.generator(x)
+        noisy, sigma = self.noise_estimator(clean)
+        return clean, noisy, sigma
 
 
 @torch.no_grad()

@@ -90,3 +90,41 @@ def test_bulk_extract_kernels_sharded(gpu_device):
     assert_close(full[3].cpu().numpy(), want, rtol=3e-4, atol=3e-7, what="bulk vs oracle")
     with pytest.raises(ValueError):
         kmsr_amd.bulk_extract_kernels([np.zeros((5, 32, 32), np.float32)], g, patch_size=64)
+
+
+def test_generator_forward_muti(gpu_device):
+    """DynamicMultiBandLinearGenerator.forward (muti_kernel/networks.py:101-133): per-layer REFLECT padding, per-sample
+    condition scales, 3 avg-pools -- against the reference's own output."""
+    g = _muti()
+    x = torch.from_numpy(KG["muti__x"]).cuda()
+    out = g(x)
+    assert tuple(out.shape) == (2, 5, 8, 8)
+    assert_close(out.cpu().numpy(), KG["muti__forward"], rtol=2e-4, atol=5e-5, what="muti forward")
+
+
+def test_generator_forward_single(gpu_device):
+    """MultiBandLinearGenerator.forward (single_kernel/networks.py:83-106), default Gaussian init and perturbed weights."""
+    x = torch.from_numpy(landsat_like((2, 5, 64, 64), 31)).cuda()
+    g = kmsr_amd.MultiBandLinearGenerator(in_ch=5, mid_ch=32).cuda()
+    assert_close(g(x).cpu().numpy(), KG["single_default__forward"], rtol=1e-4, atol=1e-3, what="single default forward")
+    g.load_state_dict(_sd("single_perturbed_sd__"), strict=True)
+    assert_close(g(x).cpu().numpy(), KG["single_perturbed__forward"], rtol=1e-4, atol=1e-3, what="single perturbed forward")
+    # odd tile coverage: a size that is not a multiple of the 16x16 workgroup tile, against the C oracle
+    x2 = torch.from_numpy(landsat_like((1, 5, 40, 56), 32)).cuda()
+    sd = {k: v.numpy() for k, v in _sd("single_perturbed_sd__").items()}
+    assert_close(g(x2).cpu().numpy(), oracle.single_generator_forward(sd, x2.cpu().numpy()), rtol=1e-4, atol=1e-3, what="40x56")
+
+
+def test_degradation_model(gpu_device):
+    """DegradationModel (muti_kernel/networks.py:227-247): the reference checkpoint layout loads unchanged; clean output ==
+    generator forward; noisy = clean + sigma * eps with the clamped per-band sigma."""
+    m = kmsr_amd.DegradationModel(in_ch=5, mid_ch=32, ks=(7, 5, 3, 1, 1, 1), scale_gain=0.1, noise_init=0.3, noise_max=1.2)
+    m.load_state_dict(_sd("muti_sd__"), strict=True)
+    m = m.cuda()
+    m.noise_estimator.noise_seed = 11
+    x = torch.from_numpy(KG["muti__x"]).cuda()
+    clean, noisy, sigma = m(x)
+    assert_close(clean.cpu().numpy(), KG["muti__forward"], rtol=2e-4, atol=5e-5, what="clean")
+    assert_close(sigma.cpu().numpy(), KG["muti__noise_sigma"], rtol=1e-6, what="sigma")
+    want = oracle.add_gaussian_noise(clean.cpu().numpy(), np.tile(sigma.cpu().numpy(), 2), seed=11, offset=0)
+    assert_close(noisy.cpu().numpy(), want, rtol=1e-6, atol=2e-6, what="noisy")
