@@ -218,6 +218,24 @@ int kmsr_conv3x3_wino_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const 
 int kmsr_conv_reflect_f32(const float* x, const float* w, int32_t U, int32_t Cin, int32_t Cout, int32_t H, int32_t W,
                           int32_t k, float* out, void* stream);
 
+/* ============================================================================================
+ * bf16 3x3 convolution (BASELINE config 4: 7-band x4 SR on 1024x1024 LR tiles -- the HBM-bound large-tile path).
+ * Activations are CHANNELS-LAST bf16 (element (n,c,y,x) at ((n*H + y)*W + x)*Cp + c, Cp = channel count padded to a
+ * multiple of 16, pad channels zero); products on v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 bias.
+ * Same epilogue semantics as kmsr_conv3x3_fwd_f32 (bias, ReLU, residual, fused PixelShuffle(2)), stride 1.
+ * Persistent workgroups keep the whole layer's packed weights in LDS and stream 8x32-pixel tiles.
+ *   d->Cin / d->Cout are the PADDED channel counts of the input / conv output (multiples of 16; Cout % 64 == 0 with
+ *   pixel_shuffle).  out is [N,H,W,Cout] (or [N,2H,2W,Cout/4] with pixel_shuffle), residual like out.
+ *   packed weights: bf16 [ceil(Cout/64)][9][64][Cin] (zero padded), from kmsr_conv3x3_bf16_pack_weights.
+ * ========================================================================================== */
+size_t kmsr_conv3x3_bf16_packed_weight_elems(int32_t Cin_p, int32_t Cout_p);
+/* w fp32 [Cout,Cin,3,3] (unpadded sizes) -> packed bf16 for padded sizes Cin_p, Cout_p */
+int kmsr_conv3x3_bf16_pack_weights(const float* w, int32_t Cin, int32_t Cout, int32_t Cin_p, int32_t Cout_p,
+                                   void* packed_bf16, void* stream);
+int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x_bf16, const void* packed_w_bf16,
+                          const float* bias /* [Cout] fp32 (padded) or NULL */, const void* residual_bf16,
+                          void* out_bf16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,274 @@
+// bf16 3x3 convolution, channels-last, on v_mfma_f32_32x32x16_bf16 (semantics: include/kmsr.h).
+//
+//   D[co, px] += A[co, k] * B[k, px],  k = 16 consecutive input channels of one tap.
+//   A lane l holds A[co = l&31][k = 8*(l>>5) + j], j < 8  -> 16 bytes of the packed weights [tap][co][ci]
+//   B lane l holds B[k = 8*(l>>5) + j][px = l&31]         -> 16 bytes of the channels-last input tile [row][col][ci]
+//   D lane l holds px = l&31 and 16 output channels (reg&3) + 8*(reg>>2) + 4*(l>>5).
+//
+// Persistent workgroups (4 waves, one per CU): the layer's packed weights for one 64-channel output group
+// ([9][64][Cin] bf16, <= 74 KB, rows padded by 16 B against bank conflicts) are loaded into LDS ONCE, then the
+// workgroup streams its share of 8x32-pixel tiles: halo tile [10][34][Cin] bf16 -> LDS, 9 taps x Cin/16 MFMA steps,
+// epilogue (bias, ReLU, bf16 rounding) written to an LDS staging tile and stored as full channel rows (16 B per lane,
+// consecutive lanes consecutive addresses), residual added in fp32 on the way out.  PixelShuffle(2) is a permutation of
+// the staging tile: conv channel 4c+2i+j of pixel (y,x) lands in channel c of pixel (2y+i, 2x+j).
+#include "kmsr_common.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace kmsr {
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr int BTH = 8, BTW = 32;          // output tile (rows x cols)
+constexpr int BIH = BTH + 2, BIW = BTW + 2;
+constexpr int BCO = 64;                   // output channels per workgroup pass
+constexpr int PADE = 8;                   // row padding in bf16 elements (16 bytes): conflict-free 16-B reads at 128-B strides
+
+// elements of the LDS region shared by the input halo tile and the output staging tile (largest of the three uses)
+__host__ __device__ constexpr int tile_region_elems(int Cin) {
+    const int a = BIH * BIW * (Cin + PADE);                  // input tile
+    const int b = BTH * BTW * (BCO + PADE);                  // staging, plain
+    const int c = (2 * BTH) * (2 * BTW) * (16 + PADE);       // staging, PixelShuffle
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
+}
+
+struct Bf16Params {
+    int N, Cin, H, W, Cout;               // padded channel counts
+    int tiles_x, tiles, cgs, n_items, relu;
+};
+
+__device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-even (NaN stays NaN via the hardware cast)
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+
+// packed[cg][tap][co 64][Cin_p] bf16  <-  w[co][ci][tap] fp32
+__global__ void bf16_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int Cin_p, int Cout_p,
+                                 unsigned short* __restrict__ packed, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(idx % Cin_p);
+        const int co = (int)((idx / Cin_p) % BCO);
+        const int tap = (int)((idx / ((long long)Cin_p * BCO)) % 9);
+        const int cg = (int)(idx / ((long long)Cin_p * BCO * 9));
+        const int cog = cg * BCO + co;
+        float v = 0.f;
+        if (cog < Cout && ci < Cin) v = w[((long long)cog * Cin + ci) * 9 + tap];
+        packed[idx] = f2bf(v);
+    }
+}
+
+template <bool PS>
+__global__ void __launch_bounds__(256, 1) conv3x3_bf16_kernel(const unsigned short* __restrict__ xg,
+                                                              const unsigned short* __restrict__ wpk,
+                                                              const float* __restrict__ bias,
+                                                              const unsigned short* __restrict__ res,
+                                                              unsigned short* __restrict__ out, Bf16Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int Cin = p.Cin, CP = Cin + PADE;                  // LDS pitch of one pixel / one weight row (elements)
+    unsigned short* wl = smem;                               // [9][64][CP]
+    unsigned short* il = smem + 9 * BCO * CP;                // [10][34][CP]   (reused as the output staging tile)
+    float* sbias = reinterpret_cast<float*>(il + tile_region_elems(Cin));   // [64]
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, W = p.W;
+    const int kvec = Cin / 8;                                // 16-byte vectors per pixel / weight row
+
+    // item = (cg, n, tile); a workgroup owns a contiguous range of items of ONE cg when possible (weights reloaded
+    // only when cg changes)
+    const int per = (p.n_items + (int)gridDim.x - 1) / (int)gridDim.x;
+    int item = blockIdx.x * per;
+    const int item_end = min(item + per, p.n_items);
+    int cur_cg = -1;
+    for (; item < item_end; ++item) {
+        const int per_cg = p.N * p.tiles;
+        const int cg = item / per_cg, rem = item % per_cg, n = rem / p.tiles, tile = rem % p.tiles;
+        const int ty0 = (tile / p.tiles_x) * BTH, tx0 = (tile % p.tiles_x) * BTW;
+        __syncthreads();                                     // previous item's staging reads are done
+        if (cg != cur_cg) {                                  // (re)load this output group's weights and bias
+            const u32x4* src = reinterpret_cast<const u32x4*>(wpk + (long long)cg * 9 * BCO * Cin);
+            for (int e = tid; e < 9 * BCO * kvec; e += 256) {
+                const int row = e / kvec, v = e % kvec;
+                *reinterpret_cast<u32x4*>(wl + row * CP + 8 * v) = src[e];
+            }
+            if (tid < BCO) sbias[tid] = (bias && cg * BCO + tid < p.Cout) ? bias[cg * BCO + tid] : 0.f;
+            cur_cg = cg;
+        }
+        // ---- input halo tile, channels-last: every pixel is Cin*2 contiguous bytes
+        const unsigned short* __restrict__ xn = xg + (long long)n * H * W * Cin;
+        for (int e = tid; e < BIH * BIW * kvec; e += 256) {
+            const int pix = e / kvec, v = e % kvec, r = pix / BIW, c = pix % BIW;
+            const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                val = *reinterpret_cast<const u32x4*>(xn + ((long long)gy * W + gx) * Cin + 8 * v);
+            *reinterpret_cast<u32x4*>(il + pix * CP + 8 * v) = val;
+        }
+        __syncthreads();
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+        const unsigned short* ap = wl + l32 * CP + 8 * half;                          // + (tap*64 + 32*mt)*CP + 16*ks
+        const unsigned short* bp = il + ((2 * wv) * BIW + l32) * CP + 8 * half;       // + ((nt+dy)*BIW + dx)*CP + 16*ks
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            for (int ks = 0; ks < Cin / 16; ++ks) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap + (tap * BCO) * CP + 16 * ks);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + (tap * BCO + 32) * CP + 16 * ks);
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bp + (dy * BIW + dx) * CP + 16 * ks);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(bp + ((1 + dy) * BIW + dx) * CP + 16 * ks);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                     // all waves are done reading the input tile -> reuse it for staging
+
+        // ---- epilogue into the staging tile.  Non-PS: st[(row*32 + col)][64 co].  PS: st[((2row+i)*64 + 2col+j)][16 c]
+        constexpr int SP = PS ? 16 + PADE : BCO + PADE;      // staging pitch (elements)
+        unsigned short* st = il;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int row = 2 * wv + nt;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co0 = mt * 32 + 8 * g + 4 * half;                      // 4 consecutive channels <-> regs 4g..4g+3
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[mt][nt][4 * g + r] + sbias[co0 + r];
+                        if (p.relu) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    if constexpr (PS) {
+                        // conv channel co0 + r = 4c + 2i + j (co0 % 4 == 0): c = co0/4, (i,j) = (r>>1, r&1)
+                        const int c = co0 >> 2;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            st[((2 * row + (r >> 1)) * (2 * BTW) + 2 * l32 + (r & 1)) * SP + c] = f2bf(v[r]);
+                    } else {
+                        const unsigned lo = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                        const unsigned hi = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(st + (row * BTW + l32) * SP + co0) = make_uint2(lo, hi);
+                    }
+                }
+            }
+        __syncthreads();
+        // ---- coalesced stores: 16-byte pieces, consecutive lanes consecutive addresses inside a pixel's channel row
+        if constexpr (PS) {
+            const int Cq = p.Cout >> 2;                       // channels of the shuffled output
+            const int H2 = 2 * H, W2 = 2 * W;
+            // staging holds [16 rows][64 cols][16 ch]; each pixel contributes 2 pieces of 8 channels at channel offset cg*16
+            for (int e = tid; e < (2 * BTH) * (2 * BTW) * 2; e += 256) {
+                const int piece = e & 1, pix = e >> 1, r = pix / (2 * BTW), c = pix % (2 * BTW);
+                const int oy = 2 * ty0 + r, ox = 2 * tx0 + c;
+                if (oy < H2 && ox < W2) {
+                    const u32x4 val = *reinterpret_cast<const u32x4*>(st + pix * SP + 8 * piece);
+                    *reinterpret_cast<u32x4*>(out + (((long long)n * H2 + oy) * W2 + ox) * Cq + cg * 16 + 8 * piece) = val;
+                }
+            }
+        } else {
+            const int pieces = min(BCO, p.Cout - cg * BCO) / 8;      // 16-byte pieces per pixel (2 for a 16-channel tail)
+            for (int e = tid; e < BTH * BTW * 8; e += 256) {
+                const int piece = e & 7, pix = e >> 3, r = pix / BTW, c = pix % BTW;
+                const int oy = ty0 + r, ox = tx0 + c;
+                if (piece < pieces && oy < H && ox < W) {
+                    u32x4 val = *reinterpret_cast<const u32x4*>(st + pix * SP + 8 * piece);
+                    const long long go = (((long long)n * H + oy) * W + ox) * p.Cout + cg * BCO + 8 * piece;
+                    if (res) {                                // block-uniform
+                        const u32x4 rv = *reinterpret_cast<const u32x4*>(res + go);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float a0 = bf2f((unsigned short)(val[q] & 0xffffu)) + bf2f((unsigned short)(rv[q] & 0xffffu));
+                            const float a1 = bf2f((unsigned short)(val[q] >> 16)) + bf2f((unsigned short)(rv[q] >> 16));
+                            val[q] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
+                        }
+                    }
+                    *reinterpret_cast<u32x4*>(out + go) = val;
+                }
+            }
+        }
+    }
+}
+
+size_t bf16_lds_bytes(int Cin) {
+    const int CP = Cin + PADE;
+    return (size_t)(9 * BCO * CP + tile_region_elems(Cin)) * 2 + BCO * sizeof(float);
+}
+
+}  // namespace
+}  // namespace kmsr
+
+using namespace kmsr;
+
+extern "C" size_t kmsr_conv3x3_bf16_packed_weight_elems(int32_t Cin_p, int32_t Cout_p) {
+    if (Cin_p <= 0 || Cout_p <= 0) return 0;
+    return (size_t)ceil_div(Cout_p, BCO) * 9 * BCO * Cin_p;
+}
+
+extern "C" int kmsr_conv3x3_bf16_pack_weights(const float* w, int32_t Cin, int32_t Cout, int32_t Cin_p, int32_t Cout_p,
+                                              void* packed, void* stream) {
+    if (!w || !packed || Cin <= 0 || Cout <= 0 || Cin_p < Cin || Cout_p < Cout || Cin_p % 16)
+        return fail(KMSR_E_BADARG, "bf16 pack: bad argument (Cin_p must be a multiple of 16 and >= Cin)");
+    const long long total = (long long)kmsr_conv3x3_bf16_packed_weight_elems(Cin_p, Cout_p);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    bf16_pack_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(w, Cin, Cout, Cin_p, Cout_p,
+                                                                          static_cast<unsigned short*>(packed), total);
+    KMSR_HIP_CHECK(hipGetLastError());
+    return KMSR_OK;
+}
+
+extern "C" int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x, const void* packed_w, const float* bias,
+                                     const void* residual, void* out, void* stream_) {
+    if (!d) return fail(KMSR_E_BADARG, "null descriptor");
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return fail(KMSR_E_BADARG, "bad conv shape");
+    if (d->stride != 1) return fail(KMSR_E_UNSUPPORTED, "bf16 conv: stride 1 only");
+    if (d->Cin % 16 || d->Cin > 64) return fail(KMSR_E_UNSUPPORTED, "bf16 conv: padded Cin must be 16, 32, 48 or 64 (got %d)", d->Cin);
+    if (d->Cout % 16) return fail(KMSR_E_UNSUPPORTED, "bf16 conv: padded Cout must be a multiple of 16 (got %d)", d->Cout);
+    if (d->pixel_shuffle && (d->Cout % 64)) return fail(KMSR_E_SHAPE, "bf16 conv: pixel_shuffle needs Cout %% 64 == 0");
+    if (!d->pixel_shuffle && (d->Cout % 64) && d->Cout > 64) return fail(KMSR_E_UNSUPPORTED, "bf16 conv: Cout > 64 must be a multiple of 64");
+    if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(out) % 16 || reinterpret_cast<uintptr_t>(residual) % 16)
+        return fail(KMSR_E_BADARG, "bf16 conv: tensors must be 16-byte aligned");
+    if (d->pixel_shuffle && residual) return fail(KMSR_E_BADARG, "residual is not supported together with pixel_shuffle");
+    if (!x || !packed_w || !out) return fail(KMSR_E_BADARG, "null tensor pointer");
+    Bf16Params p{};
+    p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.relu = d->relu;
+    p.tiles_x = ceil_div(d->W, BTW);
+    p.tiles = p.tiles_x * ceil_div(d->H, BTH);
+    p.cgs = ceil_div(d->Cout, BCO);
+    const long long items = (long long)p.tiles * p.cgs * d->N;
+    if (items > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv grid too large");
+    p.n_items = (int)items;
+    int grid = (int)std::min<long long>(items, 256);
+    if (const char* e = getenv("KMSR_BF16_GRID")) grid = std::max(1, std::min((int)items, atoi(e)));
+    const size_t shmem = bf16_lds_bytes(d->Cin);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const auto* xs = static_cast<const unsigned short*>(x);
+    const auto* ws = static_cast<const unsigned short*>(packed_w);
+    const auto* rs = static_cast<const unsigned short*>(residual);
+    auto* os = static_cast<unsigned short*>(out);
+    if (d->pixel_shuffle) {
+        KMSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        conv3x3_bf16_kernel<true><<<grid, 256, shmem, stream>>>(xs, ws, bias, rs, os, p);
+    } else {
+        KMSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        conv3x3_bf16_kernel<false><<<grid, 256, shmem, stream>>>(xs, ws, bias, rs, os, p);
+    }
+    KMSR_HIP_CHECK(hipGetLastError());
+    return KMSR_OK;
+}

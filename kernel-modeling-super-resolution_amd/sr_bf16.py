@@ -1,0 +1,101 @@
+"""bf16 inference path of the SR network (BASELINE config 4: 7-band x4 SR on 1024x1024 LR tiles, HBM-bound).
+
+Activations are channels-last bf16 with the channel count padded to a multiple of 16 ([N,H,W,Cp] contiguous); the convs
+run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (include/kmsr.h: kmsr_conv3x3_fwd_bf16).  The wrapper takes the
+SAME SRNet module (fp32 master weights, standard state_dict) and the usual [B,C,h,w] tensor and returns [B,C,4h,4w].
+"""
+import torch
+
+from . import _lib as L
+
+
+def _pad16(c):
+    return (c + 15) // 16 * 16
+
+
+def to_nhwc_bf16(x, cp=None):
+    """[N,C,H,W] (any float dtype) -> channels-last bf16 [N,H,W,Cp], zero padded channels."""
+    N, C, H, W = x.shape
+    cp = cp or _pad16(C)
+    out = torch.zeros((N, H, W, cp), device=x.device, dtype=torch.bfloat16)
+    out[..., :C] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    return out
+
+
+def from_nhwc(x, c):
+    """[N,H,W,Cp] -> [N,c,H,W] view-permuted (channels-last memory format)."""
+    return x[..., :c].permute(0, 3, 1, 2)
+
+
+def pack_conv3x3_weight_bf16(weight, cin_p, cout_p):
+    lib = L.load()
+    w = weight.detach().to(torch.float32).contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    packed = torch.empty(lib.kmsr_conv3x3_bf16_packed_weight_elems(cin_p, cout_p), device=w.device, dtype=torch.bfloat16)
+    with torch.cuda.device(w.device):
+        L.check(lib.kmsr_conv3x3_bf16_pack_weights(L.ptr(w), Cin, Cout, cin_p, cout_p, L.ptr(packed), L.current_stream()))
+    return packed
+
+
+def conv3x3_bf16(x, packed_w, cout_p, bias=None, relu=False, residual=None, pixel_shuffle=False, out=None):
+    """x [N,H,W,Cin_p] bf16 contiguous -> [N,H,W,cout_p] (or [N,2H,2W,cout_p/4]); bias fp32 [>= cout_p] or None."""
+    lib = L.load()
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.ndim == 4
+    N, H, W, cin_p = x.shape
+    d = L.Conv3x3Desc()
+    d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, cin_p, H, W, int(cout_p), 1
+    d.relu, d.pixel_shuffle = int(bool(relu)), int(bool(pixel_shuffle))
+    assert packed_w.dtype == torch.bfloat16 and packed_w.numel() == lib.kmsr_conv3x3_bf16_packed_weight_elems(cin_p, int(cout_p))
+    oshape = (N, 2 * H, 2 * W, cout_p // 4) if pixel_shuffle else (N, H, W, cout_p)
+    if out is None:
+        out = torch.empty(oshape, device=x.device, dtype=torch.bfloat16)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= cout_p
+    if residual is not None:
+        assert tuple(residual.shape) == oshape and residual.dtype == torch.bfloat16 and residual.is_contiguous()
+    with torch.cuda.device(x.device):
+        L.check(lib.kmsr_conv3x3_fwd_bf16(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out),
+                                          L.current_stream()))
+    return out
+
+
+class SRNetBF16:
+    """bf16 executor of an SRNet (weights are packed once from the module's fp32 parameters; call .refresh() after
+    changing them)."""
+
+    def __init__(self, net):
+        self.net = net
+        self.refresh()
+
+    def _prep(self, conv, cin_p, cout_p):
+        dev = conv.weight.device
+        b = torch.zeros(max(cout_p, 64), device=dev, dtype=torch.float32)
+        b[:conv.out_channels] = conv.bias.detach().float()
+        return pack_conv3x3_weight_bf16(conv.weight, cin_p, cout_p), b, cout_p
+
+    @torch.no_grad()
+    def refresh(self):
+        n = self.net
+        F = n.n_feats
+        assert F % 64 == 0 or F in (16, 32, 48), "n_feats must suit the 16-channel MFMA k-step"
+        self.cin_p = _pad16(n.n_colors)
+        self.head = self._prep(n.head, self.cin_p, F)
+        self.body = [(self._prep(b.conv1, F, F), self._prep(b.conv2, F, F)) for b in n.body]
+        self.body_tail = self._prep(n.body_tail, F, F)
+        self.up = [self._prep(u, F, 4 * F) for u in n.up]
+        self.tail = self._prep(n.tail, F, _pad16(n.n_colors))
+
+    @torch.no_grad()
+    def __call__(self, x):
+        L.require_gpu()
+        n = self.net
+        h0 = to_nhwc_bf16(x, self.cin_p)
+        cv = lambda prm, t, **kw: conv3x3_bf16(t, prm[0], prm[2], bias=prm[1], **kw)
+        f = cv(self.head, h0)
+        h = f
+        for c1, c2 in self.body:
+            h = cv(c2, cv(c1, h, relu=True), residual=h)
+        h = cv(self.body_tail, h, residual=f)
+        for u in self.up:
+            h = cv(u, h, pixel_shuffle=True)
+        return from_nhwc(cv(self.tail, h), n.n_colors)
