@@ -216,6 +216,46 @@ class DegradeSRWorkload:
                           f"SRNetTorch fp32, {el:.1f} s on {cores} threads"}
 
 
+class SRBf16Workload:
+    """BASELINE.json configs[3]: 7-band x4 SR on a 1024x1024 LR tile in bf16 (channels-last bf16 activations,
+    v_mfma_f32_32x32x16_bf16 with fp32 accumulation) -- the HBM-bound large-tile path.  One step = one tile."""
+    name = "sr_fwd_x4_lr1024_c7_bf16"
+
+    def __init__(self, device, rank, C=7, h=1024, w=1024):
+        from kmsr_amd.sr import SRNet
+        from kmsr_amd.sr_bf16 import SRNetBF16
+        self.B, self.C, self.H, self.W = 1, C, 4 * h, 4 * w
+        torch.manual_seed(0)
+        self.net = SRNet(C, 64, 16, 4).to(device).eval()
+        self.ex = SRNetBF16(self.net)
+        self.lr = synth_hr(1, C, h, w, device, seed=4000 + rank)
+        self.patches_per_step = (h // 256) * (w // 256)      # in units of the metric's 256x256 LR patches
+        self.body_bytes = 2.0 * 64 * h * w * 3               # body conv: read x, read residual, write y (bf16, 64 ch)
+        self.h, self.w = h, w
+
+    def step(self):
+        self.sr = self.ex(self.lr)
+
+    def roofline(self, step_ms):
+        from kmsr_amd.sr_bf16 import conv3x3_bf16
+        # dominant kernel timed live on the launch stream: body conv 64->64 with residual at the tile size
+        x = torch.randn(1, self.h, self.w, 64, device=self.lr.device).to(torch.bfloat16)
+        prm = self.ex.body[0][1]
+        out = torch.empty_like(x)
+        conv3x3_bf16(x, prm[0], prm[2], bias=prm[1], residual=x, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            conv3x3_bf16(x, prm[0], prm[2], bias=prm[1], residual=x, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        ach = self.body_bytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "conv3x3_bf16_kernel<false> (64->64 + residual @1024x1024, channels-last bf16)",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": None, "algorithmic_bytes_per_launch": self.body_bytes, "kernel_ms": round(ms, 4)}
+
+
 class TrainWorkload:
     """BASELINE.json configs[2]: SR x4 TRAINING step with on-the-fly degradation from the 10-kernel pool, batch 32 per GPU,
     data parallel: HR [32,5,1024,1024] --fused V-B degradation (random kernel of the bank per sample, Gaussian sigma)-->
@@ -270,7 +310,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["degrade_sr", "degrade", "train"], default="degrade_sr")
+    ap.add_argument("--workload", choices=["degrade_sr", "degrade", "train", "sr_bf16"], default="degrade_sr")
     args = ap.parse_args()
 
     from kmsr_amd import dist as kd
@@ -279,7 +319,7 @@ def main():
     device = torch.device("cuda", local if world > 1 else 0)
     L.require_gpu()
 
-    wl = {"degrade_sr": DegradeSRWorkload, "degrade": DegradeWorkload, "train": TrainWorkload}[args.workload](device, rank)
+    wl = {"degrade_sr": DegradeSRWorkload, "degrade": DegradeWorkload, "train": TrainWorkload, "sr_bf16": SRBf16Workload}[args.workload](device, rank)
     for _ in range(max(args.warmup, 1)):
         wl.step()
     if hasattr(wl, "instrument"):
@@ -314,7 +354,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16" if args.workload == "sr_bf16" else "f32",
             "data": "synthetic",
             "config": {"workload": wl.name, "hr": [wl.B, wl.C, wl.H, wl.W], "factor": 4,
                        "sharding": f"independent patches, {wl.B}/GPU, no data-path collective"},
