@@ -101,13 +101,27 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_kernel(const unsigned sho
         }
         // ---- input halo tile, channels-last: every pixel is Cin*2 contiguous bytes
         const unsigned short* __restrict__ xn = xg + (long long)n * H * W * Cin;
-        for (int e = tid; e < BIH * BIW * kvec; e += 256) {
-            const int pix = e / kvec, v = e % kvec, r = pix / BIW, c = pix % BIW;
-            const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                val = *reinterpret_cast<const u32x4*>(xn + ((long long)gy * W + gx) * Cin + 8 * v);
-            *reinterpret_cast<u32x4*>(il + pix * CP + 8 * v) = val;
+        {
+            // all loads are issued before any is consumed (a rolled load->store loop would pay one memory round trip
+            // per iteration): <= 11 x 16 bytes per thread for Cin = 64
+            constexpr int NLD = (BIH * BIW * 8 + 255) / 256;
+            const int n_in = BIH * BIW * kvec;
+            u32x4 vals[NLD];
+#pragma unroll
+            for (int t = 0; t < NLD; ++t) {
+                const int e = tid + 256 * t;
+                const int pix = e / kvec, v = e - pix * kvec, r = pix / BIW, c = pix - r * BIW;
+                const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
+                const bool ok = e < n_in && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const u32x4 ld = *reinterpret_cast<const u32x4*>(xn + (ok ? ((long long)gy * W + gx) * Cin + 8 * v : 0));
+                vals[t] = ok ? ld : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int t = 0; t < NLD; ++t) {
+                const int e = tid + 256 * t;
+                const int pix = e / kvec, v = e - pix * kvec;
+                if (e < n_in) *reinterpret_cast<u32x4*>(il + pix * CP + 8 * v) = vals[t];
+            }
         }
         __syncthreads();
 
@@ -182,23 +196,36 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_kernel(const unsigned sho
             }
         } else {
             const int pieces = min(BCO, p.Cout - cg * BCO) / 8;      // 16-byte pieces per pixel (2 for a 16-channel tail)
-            for (int e = tid; e < BTH * BTW * 8; e += 256) {
+            constexpr int NST = BTH * BTW * 8 / 256;                  // 8 pieces per thread
+            long long go[NST];
+            bool ok[NST];
+            u32x4 rv[NST];
+#pragma unroll
+            for (int t = 0; t < NST; ++t) {
+                const int e = tid + 256 * t;
                 const int piece = e & 7, pix = e >> 3, r = pix / BTW, c = pix % BTW;
                 const int oy = ty0 + r, ox = tx0 + c;
-                if (piece < pieces && oy < H && ox < W) {
-                    u32x4 val = *reinterpret_cast<const u32x4*>(st + pix * SP + 8 * piece);
-                    const long long go = (((long long)n * H + oy) * W + ox) * p.Cout + cg * BCO + 8 * piece;
-                    if (res) {                                // block-uniform
-                        const u32x4 rv = *reinterpret_cast<const u32x4*>(res + go);
+                ok[t] = piece < pieces && oy < H && ox < W;
+                go[t] = ok[t] ? (((long long)n * H + oy) * W + ox) * p.Cout + cg * BCO + 8 * piece : 0;
+                rv[t] = u32x4{0u, 0u, 0u, 0u};
+            }
+            if (res) {                                                // block-uniform: all residual pieces in flight together
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float a0 = bf2f((unsigned short)(val[q] & 0xffffu)) + bf2f((unsigned short)(rv[q] & 0xffffu));
-                            const float a1 = bf2f((unsigned short)(val[q] >> 16)) + bf2f((unsigned short)(rv[q] >> 16));
-                            val[q] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
-                        }
+                for (int t = 0; t < NST; ++t) rv[t] = *reinterpret_cast<const u32x4*>(res + go[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < NST; ++t) {
+                const int e = tid + 256 * t;
+                u32x4 val = *reinterpret_cast<const u32x4*>(st + (e >> 3) * SP + 8 * (e & 7));
+                if (res) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float a0 = bf2f((unsigned short)(val[q] & 0xffffu)) + bf2f((unsigned short)(rv[t][q] & 0xffffu));
+                        const float a1 = bf2f((unsigned short)(val[q] >> 16)) + bf2f((unsigned short)(rv[t][q] >> 16));
+                        val[q] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
                     }
-                    *reinterpret_cast<u32x4*>(out + go) = val;
                 }
+                if (ok[t]) *reinterpret_cast<u32x4*>(out + go[t]) = val;
             }
         }
     }

@@ -24,10 +24,22 @@ __global__ void __launch_bounds__(256) conv_reflect_kernel(const float* __restri
     const int u = blockIdx.x / tiles, t = blockIdx.x % tiles;
     const int ty0 = (t / tiles_x) * RT, tx0 = (t % tiles_x) * RT;
     const float* __restrict__ xu = x + (long long)u * Cin * H * W;
-    for (int e = tid; e < Cin * IT * IT; e += 256) {
-        const int c = e / (IT * IT), rem = e - c * (IT * IT), r = rem / IT, cc = rem - r * IT;
-        const int gy = reflect_idx(min(ty0 + r - P, H - 1 + P), H), gx = reflect_idx(min(tx0 + cc - P, W - 1 + P), W);
-        tile[e] = xu[((long long)c * H + gy) * W + gx];
+    // 8 loads in flight per thread before any is written to LDS (a rolled load->store loop pays a round trip per element)
+    const int n_el = Cin * IT * IT;
+    for (int e0 = 0; e0 < n_el; e0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = min(e0 + tid + 256 * q, n_el - 1);
+            const int c = e / (IT * IT), rem = e - c * (IT * IT), r = rem / IT, cc = rem - r * IT;
+            const int gy = reflect_idx(min(ty0 + r - P, H - 1 + P), H), gx = reflect_idx(min(tx0 + cc - P, W - 1 + P), W);
+            v[q] = xu[((long long)c * H + gy) * W + gx];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + tid + 256 * q;
+            if (e < n_el) tile[e] = v[q];
+        }
     }
     __syncthreads();
     const int py = tid / RT, px = tid % RT;
