@@ -172,3 +172,44 @@ def test_srnet_repacks_after_weight_update(gpu_device):
     assert torch.allclose(net(x), 2 * y0, rtol=1e-5, atol=1e-6)
     with pytest.raises(L.KmsrError):
         net(x.cpu())
+
+
+def test_full_config2_size_consistency(gpu_device):
+    """BASELINE config 2 size ([16,3,256,256] LR): the oracle would take minutes here, so use size-independent
+    properties: (1) the Winograd and direct kernels agree on the body layer at full size, (2) the whole network agrees
+    between its two inference algorithms, (3) per-image independence: batch of 16 == 16 batches of 1 (bit-exact: the
+    tiling never mixes images), (4) with the residual branches zeroed the network reduces to head -> upsampler -> tail."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(16, 64, 256, 256, device="cuda", generator=g)
+    w = torch.randn(64, 64, 3, 3, device="cuda", generator=g) / 24.0
+    b = torch.randn(64, device="cuda", generator=g)
+    from kmsr_amd.sr import pack_conv3x3_weight_wino
+    d = conv3x3(x, pack_conv3x3_weight(w), 64, bias=b, relu=True)
+    wi = conv3x3(x, pack_conv3x3_weight_wino(w), 64, bias=b, relu=True, algo="winograd")
+    scale = float(d.abs().mean())
+    assert float((d - wi).abs().max()) < 2e-5 * (float(d.abs().max()) + scale)
+    torch.manual_seed(0)
+    net = SRNet(3, 64, 16, 4).cuda().eval()
+    lr = torch.rand(16, 3, 256, 256, device="cuda", generator=g) * 80 + 20
+    net.use_winograd = True
+    y_w = net(lr)
+    net.use_winograd = False
+    y_d = net(lr)
+    assert tuple(y_w.shape) == (16, 3, 1024, 1024)
+    assert float((y_w - y_d).abs().max() / y_d.abs().max()) < 1e-4
+    net.use_winograd = True
+    y_1 = torch.cat([net(lr[i:i + 1]) for i in (0, 7, 15)])
+    assert torch.equal(y_1, y_w[[0, 7, 15]])
+    with torch.no_grad():
+        for blk in net.body:
+            blk.conv2.weight.zero_()
+            blk.conv2.bias.zero_()
+        net.body_tail.weight.zero_()
+        net.body_tail.bias.zero_()
+    # every residual branch (conv2, body_tail) is exactly zero now, so the trunk output is head(x) itself
+    h = conv3x3(lr, pack_conv3x3_weight(net.head.weight), 64, bias=net.head.bias)
+    for up in net.up:
+        h = conv3x3(h, pack_conv3x3_weight(up.weight), 256, bias=up.bias, pixel_shuffle=True)
+    want = conv3x3(h, pack_conv3x3_weight(net.tail.weight), 3, bias=net.tail.bias)
+    got = net(lr)
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-4
