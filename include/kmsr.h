@@ -236,6 +236,26 @@ int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x_bf16, const 
                           const float* bias /* [Cout] fp32 (padded) or NULL */, const void* residual_bf16,
                           void* out_bf16, void* stream);
 
+/* ============================================================================================
+ * Patch cutting with a water mask -- the step that FEEDS the path.
+ * Replaces apply_water_mask / create_patches_nc   kernel_from_lr_gan/A_00_patch_cutter_universal.py:89-197
+ *   water mask : v == invalid_value -> NaN (every band);  water = tmin <= NIR <= tmax (NaN compares false);
+ *                masked[c] = water ? v[c] : NaN;   counts[0] = #(NIR not NaN), counts[1] = #water   (:102-121)
+ *   patch grid : stride = int(ps * stride_ratio) (host), hp = (H-ps)/stride+1, wp = (W-ps)/stride+1 (:149-153);
+ *                nan_counts[i*wp+j] = number of NaN in data[:, i*stride:+ps, j*stride:+ps]  (:171) -- an INTEGER, so the
+ *                caller's `count / patch.size > nan_threshold` test reproduces the reference's decision exactly
+ *   gather     : out[t] = data[:, tl[t][0]:+ps, tl[t][1]:+ps]
+ * All counts are exact integer reductions (integer atomics only).
+ * ========================================================================================== */
+int kmsr_water_mask_f32(const float* data, int32_t C, int32_t H, int32_t W, int32_t nir_index, float invalid_value,
+                        float tmin, float tmax, float* masked, uint64_t* counts /* device [2], zeroed by the call */,
+                        void* stream);
+int kmsr_patch_nan_counts_f32(const float* data, int32_t C, int32_t H, int32_t W, int32_t ps, int32_t stride,
+                              int32_t* nan_counts /* device [hp*wp] */, void* stream);
+int kmsr_gather_patches_f32(const float* data, int32_t C, int32_t H, int32_t W, int32_t ps,
+                            const int32_t* top_left /* device [n][2] */, int32_t n, float* out /* [n,C,ps,ps] */,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -279,5 +279,53 @@ def main():
             print(f"{f:28s} {os.path.getsize(os.path.join(OUT, f)) / 1024:9.1f} KiB")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--patch-cutter" not in sys.argv:
     main()
+
+
+def patch_cutter_scene(seed=0, H=700, W=900):
+    """Synthetic mostly-water scene for the patch cutter: 5 bands, NIR (band 4) in [0.5, 6.5) over water, land blobs with
+    NIR 50, blocks of the invalid marker -9999.  Regenerated from the seed by the tests (NumPy RandomState is portable)."""
+    rs = np.random.RandomState(seed)
+    data = (rs.rand(5, H, W) * 6.0 + 0.5).astype(np.float32)
+    data[4, 300:380, 100:400] = 50.0          # land: NIR above THRESHOLD_MAX
+    data[4, 20:25, 600:640] = 0.0             # below THRESHOLD_MIN
+    data[:, 100:140, 200:260] = -9999.0       # invalid marker in all bands
+    data[2, 600:601, 850:851] = -9999.0       # a single invalid value in one band only
+    return data
+
+
+def make_patch_cutter_golden():
+    """A_00_patch_cutter_universal.py:89-197: apply_water_mask + create_patches_nc (its NetCDF writer replaced by a recorder)."""
+    import contextlib
+    import io
+    import tempfile
+    stub = types.ModuleType("netCDF4")
+    stub.Dataset = object
+    sys.modules["netCDF4"] = stub
+    pc = _load("ref_patch_cutter", os.path.join(REF, "kernel_from_lr_gan", "A_00_patch_cutter_universal.py"))
+    data = patch_cutter_scene()
+    rec = []
+    pc.save_patch_as_nc = lambda patch, path, metadata, i, j, hs, ws: rec.append(
+        (i, j, hs, ws, int(np.isnan(patch).sum()), float(np.nansum(patch.astype(np.float64)))))
+    out = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        masked = pc.apply_water_mask(data.copy(), pc.THRESHOLD_MIN, pc.THRESHOLD_MAX)
+        for tag, thr, ps, sr in (("thr0", 0.0, 256, 0.5), ("thr002", 0.02, 256, 0.5), ("ps128", 0.01, 128, 0.75)):
+            rec.clear()
+            tot, kept = pc.create_patches_nc(masked, ps, sr, thr, tempfile.mkdtemp(), "p", {})
+            out[tag + "__total_kept"] = np.array([tot, kept], np.int64)
+            out[tag + "__rec"] = np.array([r[:5] for r in rec], np.int64).reshape(-1, 5)
+            out[tag + "__sums"] = np.array([r[5] for r in rec], np.float64)
+            out[tag + "__args"] = np.array([thr, ps, sr], np.float64)
+    out["masked_nan_count"] = np.array([int(np.isnan(masked).sum())], np.int64)
+    out["masked_nan_rowsum"] = np.isnan(masked).sum(axis=(0, 2)).astype(np.int64)
+    out["masked_sum"] = np.array([float(np.nansum(masked.astype(np.float64)))])
+    out["consts"] = np.array([pc.THRESHOLD_MIN, pc.THRESHOLD_MAX, pc.INVALID_VALUE, pc.NIR_BAND_INDEX], np.float64)
+    out["note"] = np.array("A_00_patch_cutter_universal.py:89-197; scene = make_golden.patch_cutter_scene(seed 0)")
+    np.savez_compressed(os.path.join(OUT, "patch_cutter.npz"), **out)
+    print({k: (v.tolist() if v.size <= 3 else v.shape) for k, v in out.items() if k.endswith("total_kept") or k == "masked_nan_count"})
+
+
+if __name__ == "__main__":
+    make_patch_cutter_golden()
