@@ -256,6 +256,19 @@ int kmsr_gather_patches_f32(const float* data, int32_t C, int32_t H, int32_t W, 
                             const int32_t* top_left /* device [n][2] */, int32_t n, float* out /* [n,C,ps,ps] */,
                             void* stream);
 
+/* ============================================================================================
+ * Non-local-means denoise of one band (the denoise/ stage).  PARITY UNPINNED: the reference
+ * calls scikit-image `denoise_nl_means(fast_mode=True, patch_size=7, patch_distance=11)` (denoise/denoise.py:55-62),
+ * which is neither vendored, versioned nor installable here; this entry point implements the published fast-mode
+ * algorithm as restated in oracle/nlm.py (the only checker available):
+ *   v = reflect-padded image; for every shift t in [-d,d]^2:
+ *   D_t(p) = sum over the box rows (r-3, r+3], cols (c-3, c+3] of (v[x] - v[x+t])^2 - 2 sigma^2;  dist = max(D,0) / (h^2 * 49)
+ *   out[p] = sum_t w v[p+t] / sum_t w,   w = exp(-dist) if dist <= 5 else 0.
+ *   img [B,H,W] (NaN-free), h [B], sigma [B] device arrays (one denoising strength per band); min(H,W) > d + 4.
+ * ========================================================================================== */
+int kmsr_nlm_f32(const float* img, int32_t B, int32_t H, int32_t W, int32_t patch_size, int32_t patch_distance,
+                 const float* h, const float* sigma, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,7 @@ SYMBOLS = {
     "kmsr_water_mask_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp]),
     "kmsr_patch_nan_counts_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "kmsr_gather_patches_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "kmsr_nlm_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "kmsr_conv_reflect_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "kmsr_compose_kernels_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
                                            _vp, _vp]),
