@@ -311,6 +311,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["degrade_sr", "degrade", "train", "sr_bf16"], default="degrade_sr")
+    ap.add_argument("--fuse-upsampler", action="store_true",
+                    help="degrade_sr: time the headline with the collapsed upsampler (one conv5x5+PS4 instead of up1/up2/tail; "
+                         "same outputs).  Off by default: the headline runs every layer as its own kernel and the collapsed "
+                         "form is reported beside it under \"variants\".")
     args = ap.parse_args()
 
     from kmsr_amd import dist as kd
@@ -325,20 +329,42 @@ def main():
     if hasattr(wl, "instrument"):
         wl.instrument(True)
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    kd.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record()                       # on torch's current stream == the stream the kernels are launched on
-    for _ in range(args.steps):
-        wl.step()
-    ev1.record()
-    torch.cuda.synchronize()
-    kd.barrier()
-    torch.cuda.synchronize()
-    elapsed = kd.max_over_ranks(time.perf_counter() - t0, device=device)     # slowest rank defines the job's time
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    def timed(steps):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        kd.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record()                       # on torch's current stream == the stream the kernels are launched on
+        for _ in range(steps):
+            wl.step()
+        ev1.record()
+        torch.cuda.synchronize()
+        kd.barrier()
+        torch.cuda.synchronize()
+        el = kd.max_over_ranks(time.perf_counter() - t0, device=device)     # slowest rank defines the job's time
+        return el, ev0.elapsed_time(ev1) / steps
+
+    if args.workload == "degrade_sr" and args.fuse_upsampler:
+        wl.net.fuse_upsampler = True
+        for _ in range(2):
+            wl.step()
+    elapsed, kernel_ms = timed(args.steps)
+    variants = None
+    if args.workload == "degrade_sr" and not args.fuse_upsampler:
+        # same job with the upsampler collapsed (identical outputs within fp32 rounding, tests/test_conv_gpu.py); reported
+        # beside the headline, never as `value`
+        wl.instrument(False)
+        wl.net.fuse_upsampler = True
+        for _ in range(2):
+            wl.step()
+        el2, _ = timed(args.steps)
+        wl.net.fuse_upsampler = False
+        variants = {"collapsed_upsampler": {
+            "value": round(wl.patches_per_step * args.steps * world / el2, 2), "unit": "LR patches/s",
+            "ms_per_step": round(el2 / args.steps * 1e3, 4),
+            "what": "up1/PS/up2/PS/tail (linear) run as ONE conv5x5 64->48 + PixelShuffle(4) launch + exact 4-px frame strips; "
+                    "same SR output (max rel diff ~2e-6)"}}
 
     if rank == 0:
         total_patches = wl.patches_per_step * args.steps * world
@@ -360,6 +386,10 @@ def main():
                        "sharding": f"independent patches, {wl.B}/GPU, no data-path collective"},
             "roofline": wl.roofline(kernel_ms),
         }
+        if args.workload == "degrade_sr":
+            out["config"]["upsampler"] = "collapsed conv5x5+PS4" if args.fuse_upsampler else "layer-by-layer"
+        if variants:
+            out["variants"] = variants
         if not args.no_cpu_baseline and world == 1 and hasattr(wl, "cpu_baseline"):
             out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -196,8 +196,9 @@ int kmsr_conv3x3_wgrad_f32(const kmsr_conv3x3_desc* d, const float* x, const flo
  * Winograd F(2x2,3x3) variant of the stride-1 forward convolution (same semantics and epilogues as
  * kmsr_conv3x3_fwd_f32; exact fp32 arithmetic re-associated: Y = A^T[(G g G^T) .* (B^T d B)]A, 2.25x fewer MFMAs).
  * The 16 transform-domain products are 16 independent [Cout x Cin] x [Cin x tiles] GEMMs on the fp32 matrix cores;
- * each wave keeps all 16 accumulator tiles (256 AGPRs, one workgroup per CU) so the output transform is lane-local.
- * Weights are consumed pre-transformed: packed layout [ceil(Cout/64)][ceil(Cin/8)][16][8][64] = G g G^T.
+ * a workgroup of 8 waves (one per CU) computes 64 channels x 64 2x2-tiles; the two waves of a SIMD split the 16
+ * transform points and exchange partial output transforms through LDS.
+ * Weights are consumed pre-transformed: packed layout [ceil(Cout/64)][ceil(Cin/16)][16][16][64] = G g G^T.
  * Intended for Cin >= 16 and Cout >= 32 (the SR body / upsampler convs); numerically within ~1e-6 of the direct kernel.
  * ========================================================================================== */
 size_t kmsr_conv3x3_wino_packed_weight_floats(int32_t Cin, int32_t Cout);
@@ -205,6 +206,22 @@ int kmsr_conv3x3_wino_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int3
                                        void* stream);
 int kmsr_conv3x3_wino_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
                               const float* residual, float* out, void* stream);
+
+/* ============================================================================================
+ * 5x5 convolution (zero padding 2) with PixelShuffle(4) fused into the store -- the COLLAPSED SR upsampler.
+ * up1 (3x3 F->4F) -> PixelShuffle(2) -> up2 (3x3 F->4F) -> PixelShuffle(2) -> tail (3x3 F->bands) contains no
+ * non-linearity, so away from the image border it equals one 5x5 convolution F -> 16*bands on the LR grid followed
+ * by PixelShuffle(4): ~10x fewer flops and no HR-sized feature maps.  The caller composes the 5x5 weights/bias from
+ * the three layers and recomputes the outer 4-pixel HR frame (up2's and tail's own zero padding reach 3 pixels) with
+ * the layer-by-layer kernels (kmsr_amd/sr.py: SRNet.fuse_upsampler).
+ *   out[n, co>>4, 4y + ((co>>2)&3), 4x + (co&3)] = bias[co] + sum_{ci,u,v} w[co,ci,u,v] * x[n,ci,y+u-2,x+v-2]
+ *   x [N,Cin,H,W], w [Cout,Cin,5,5] with Cout % 16 == 0, out [N,Cout/16,4H,4W].  fp32 MFMA implicit GEMM.
+ * ========================================================================================== */
+size_t kmsr_conv5x5_ps4_packed_weight_floats(int32_t Cin, int32_t Cout);
+int kmsr_conv5x5_ps4_pack_weights_f32(const float* w /* [Cout,Cin,5,5] */, int32_t Cin, int32_t Cout, float* packed,
+                                      void* stream);
+int kmsr_conv5x5_ps4_fwd_f32(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, const float* x,
+                             const float* packed_w, const float* bias, float* out, void* stream);
 
 /* ============================================================================================
  * Small-channel convolution with REFLECT padding and per-unit weights -- the KernelGAN generators' forward

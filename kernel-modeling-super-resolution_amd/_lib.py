@@ -73,6 +73,9 @@ SYMBOLS = {
     "kmsr_patch_nan_counts_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "kmsr_gather_patches_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "kmsr_nlm_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "kmsr_conv5x5_ps4_packed_weight_floats": (_sz, [_i32, _i32]),
+    "kmsr_conv5x5_ps4_pack_weights_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "kmsr_conv5x5_ps4_fwd_f32": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "kmsr_conv_reflect_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "kmsr_compose_kernels_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
                                            _vp, _vp]),

@@ -152,6 +152,131 @@ class _PackCache:
         return self.packed
 
 
+def compose_upsampler(up1, up2, tail):
+    """Collapse  tail(PS2(up2(PS2(up1(h)))))  -- linear, no activation in between -- into one 5x5 convolution on the LR
+    grid followed by PixelShuffle(4):  -> (w5 [16*bands, F, 5, 5], b5 [16*bands]) float32 on the CPU.
+
+    The composite taps are read off the chain's response to unit impulses (and to a zero image for the bias), evaluated
+    in float64 so the only rounding is the final cast; host-side weight preparation like pack_conv3x3_weight, done once
+    per weight version.  Exact wherever tail and up2 read only in-image data: HR pixels >= 3 from the border (up1's zero padding of the
+    LR input is reproduced by the 5x5 kernel's own zero padding)."""
+    import torch.nn.functional as Fn
+    F, bands = up1.in_channels, tail.out_channels
+    cvt = lambda t: t.detach().to("cpu", torch.float64)
+
+    def chain(h, with_bias):
+        for cv in (up1, up2):
+            h = Fn.pixel_shuffle(Fn.conv2d(h, cvt(cv.weight), cvt(cv.bias) if with_bias and cv.bias is not None else None,
+                                           padding=1), 2)
+        return Fn.conv2d(h, cvt(tail.weight), cvt(tail.bias) if with_bias and tail.bias is not None else None, padding=1)
+
+    S, c0 = 11, 5
+    imp = torch.zeros(F, F, S, S, dtype=torch.float64)
+    imp[torch.arange(F), torch.arange(F), c0, c0] = 1.0
+    r = chain(imp, False)                                           # [ci, band, 4S, 4S]
+    # out[band, 4Y+a, 4X+b] = w5[band*16+a*4+b, ci, dy, dx] with Y = c0 + 2 - dy, X = c0 + 2 - dx
+    r = r[:, :, 4 * (c0 - 2):4 * (c0 + 3), 4 * (c0 - 2):4 * (c0 + 3)].reshape(F, bands, 5, 4, 5, 4)   # [ci,band,Yi,a,Xi,b]
+    r = r.flip(2).flip(4)                                           # Yi = 4 - dy -> dy
+    w5 = r.permute(1, 3, 5, 0, 2, 4).reshape(bands * 16, F, 5, 5)
+    z = chain(torch.zeros(1, F, S, S, dtype=torch.float64), True)
+    b5 = z[0, :, 4 * c0:4 * c0 + 4, 4 * c0:4 * c0 + 4].reshape(bands * 16)
+    return w5.float().contiguous(), b5.float().contiguous()
+
+
+def conv5x5_ps4(x, packed_w, cout, bias=None, out=None):
+    """out[n, co>>4, 4y+((co>>2)&3), 4x+(co&3)] = bias[co] + conv5x5(x, w)[co] (zero pad 2): kmsr_conv5x5_ps4_fwd_f32."""
+    lib = L.load()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.ndim == 4):
+        raise ValueError("x must be a 4-D float32 CUDA tensor")
+    x = x.contiguous()
+    N, Cin, H, W = x.shape
+    assert packed_w.is_cuda and packed_w.numel() == lib.kmsr_conv5x5_ps4_packed_weight_floats(Cin, int(cout))
+    oshape = (N, cout // 16, 4 * H, 4 * W)
+    if out is None:
+        out = torch.empty(oshape, device=x.device, dtype=torch.float32)
+    else:
+        assert tuple(out.shape) == oshape and out.is_contiguous() and out.dtype == torch.float32
+    if bias is not None:
+        assert bias.is_cuda and bias.numel() == cout and bias.is_contiguous()
+    with torch.cuda.device(x.device):
+        L.check(lib.kmsr_conv5x5_ps4_fwd_f32(N, Cin, H, W, int(cout), L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(out),
+                                             L.current_stream()))
+    return out
+
+
+class _FusedUpsampler:
+    """Inference-time executor of the collapsed x4 upsampler (SRNet.fuse_upsampler):
+    interior = one conv5x5_ps4 launch on the composed weights; the outer HR frame (3 pixels are affected by the zero
+    padding of up2 and tail; 4 are rewritten) is recomputed exactly by running the three layers on four 4-row LR strips (left/right strips transposed,
+    with transposed taps and PixelShuffle sub-pixel order swapped, so every strip is a wide 4-row image)."""
+    R = 4            # LR rows per strip: the layer-by-layer result is exact for HR rows [0, 4R-8]
+    FRAME = 4        # HR frame overwritten (the composed operator is exact from HR row/col 3 inwards)
+
+    def __init__(self):
+        self.key = None
+
+    @staticmethod
+    def _swap_subpixels(conv):
+        """Weights/bias of the conv that acts on TRANSPOSED images: taps transposed, PixelShuffle channel 4c+2i+j <- 4c+2j+i."""
+        co = torch.arange(conv.out_channels, device=conv.weight.device)
+        src = (co & ~3) | ((co & 1) << 1) | ((co >> 1) & 1)
+        w = conv.weight.detach()[src].transpose(2, 3).contiguous()
+        b = conv.bias.detach()[src].contiguous() if conv.bias is not None else None
+        return w, b
+
+    def _prepare(self, net):
+        up1, up2 = net.up
+        tensors = [t for cv in (up1, up2, net.tail) for t in (cv.weight, cv.bias) if t is not None]
+        key = tuple((t.data_ptr(), t._version, t.device) for t in tensors) + (net.use_winograd,)
+        if key == self.key:
+            return
+        dev = up1.weight.device
+        w5, b5 = compose_upsampler(up1, up2, net.tail)
+        w5 = w5.to(dev)
+        self.cout5 = w5.shape[0]
+        lib = L.load()
+        self.w5 = torch.empty(lib.kmsr_conv5x5_ps4_packed_weight_floats(w5.shape[1], w5.shape[0]), device=dev,
+                              dtype=torch.float32)
+        with torch.cuda.device(dev):
+            L.check(lib.kmsr_conv5x5_ps4_pack_weights_f32(L.ptr(w5), w5.shape[1], w5.shape[0], L.ptr(self.w5),
+                                                          L.current_stream()))
+        self.b5 = b5.to(dev)
+        # layer-by-layer weights for the frame strips: as stored (top/bottom) and for transposed strips (left/right)
+        self.layers = {}
+        for tag in ("n", "t"):
+            ls = []
+            for cv in (up1, up2, net.tail):
+                if tag == "n":
+                    w, b = cv.weight.detach().contiguous(), (cv.bias.detach().contiguous() if cv.bias is not None else None)
+                elif cv is net.tail:
+                    w, b = cv.weight.detach().transpose(2, 3).contiguous(), (cv.bias.detach().contiguous() if cv.bias is not None else None)
+                else:
+                    w, b = self._swap_subpixels(cv)
+                ls.append((w, b, pack_conv3x3_weight(w), pack_conv3x3_weight_wino(w) if winograd_eligible(w.shape[1], w.shape[0]) else None))
+            self.layers[tag] = ls
+        self.key = key
+
+    def _chain(self, tag, s, use_wino):
+        """up1 -> PS -> up2 -> PS -> tail on a strip batch [M,F,R,L] with the HIP 3x3 kernels."""
+        for i, (w, b, pk, pkw) in enumerate(self.layers[tag]):
+            wino = use_wino and pkw is not None and winograd_eligible(w.shape[1], w.shape[0], 1, s.shape[-1])
+            s = conv3x3(s, pkw if wino else pk, w.shape[0], bias=b, pixel_shuffle=i < 2, algo="winograd" if wino else "direct")
+        return s
+
+    def __call__(self, net, h):
+        self._prepare(net)
+        N, F, H, W = h.shape
+        R, E = self.R, self.FRAME
+        y = conv5x5_ps4(h, self.w5, self.cout5, bias=self.b5)
+        tb = self._chain("n", torch.cat([h[:, :, :R, :], h[:, :, H - R:, :]], 0), net.use_winograd)          # [2N,C,4R,4W]
+        y[:, :, :E, :] = tb[:N, :, :E, :]
+        y[:, :, 4 * H - E:, :] = tb[N:, :, 4 * R - E:, :]
+        lr = self._chain("t", torch.cat([h[:, :, :, :R], h[:, :, :, W - R:]], 0).transpose(2, 3), net.use_winograd)  # [2N,C,4R,4H]
+        y[:, :, :, :E] = lr[:N, :, :E, :].transpose(2, 3)
+        y[:, :, :, 4 * W - E:] = lr[N:, :, 4 * R - E:, :].transpose(2, 3)
+        return y
+
+
 class ResBlock(nn.Module):
     def __init__(self, n_feats):
         super().__init__()
@@ -174,6 +299,8 @@ class SRNet(nn.Module):
         self.tail = nn.Conv2d(n_feats, n_colors, 3, padding=1)
         self._caches = {}
         self.use_winograd = True    # inference path: Winograd F(2x2,3x3) MFMA kernel for the F->F / F->4F convs
+        self.fuse_upsampler = False  # inference path, x4 only: collapse up1/PS/up2/PS/tail into one 5x5 conv + PS4 (opt-in)
+        self._fused_up = _FusedUpsampler()
 
     def _packed(self, name, conv, wino=False):
         c = self._caches.get(name)
@@ -217,6 +344,8 @@ class SRNet(nn.Module):
             t = self._conv(f"b{i}.1", blk.conv1, h, relu=True)
             h = self._conv(f"b{i}.2", blk.conv2, t, residual=h)
         h = self._conv("body_tail", self.body_tail, h, residual=f)
+        if self.fuse_upsampler and len(self.up) == 2 and min(h.shape[-2:]) >= 2 * _FusedUpsampler.R:
+            return self._fused_up(self, h)
         for i, up in enumerate(self.up):
             h = self._conv(f"up{i}", up, h, pixel_shuffle=True)      # conv F->4F with PixelShuffle(2) fused into the store
         return self._conv("tail", self.tail, h)

@@ -135,3 +135,21 @@ def test_random_crop_matches_reference_stream():
     assert all(c.shape == (5, 32, 32) for c in crops)
     with pytest.raises(ValueError):
         kmsr_amd.random_crop(data[:, :16], 32, 1)
+
+
+def test_compose_upsampler_is_the_interior_operator():
+    """Host-side check (no GPU call): the composed 5x5 weights reproduce up1/PS/up2/PS/tail from HR pixel 3 inwards."""
+    import torch
+    import torch.nn.functional as F
+    from kmsr_amd.sr import SRNet, compose_upsampler
+    torch.manual_seed(3)
+    net = SRNet(3, 16, 1, 4)
+    w5, b5 = compose_upsampler(net.up[0], net.up[1], net.tail)
+    h = torch.randn(2, 16, 12, 14, dtype=torch.float64)
+    r = h
+    for cv in net.up:
+        r = F.pixel_shuffle(F.conv2d(r, cv.weight.detach().double(), cv.bias.detach().double(), padding=1), 2)
+    r = F.conv2d(r, net.tail.weight.detach().double(), net.tail.bias.detach().double(), padding=1)
+    f = F.pixel_shuffle(F.conv2d(h, w5.double(), b5.double(), padding=2), 4)
+    d = (r - f).abs()
+    assert float(d[:, :, 3:-3, 3:-3].max()) < 1e-6 and float(d.max()) > 1e-3   # the frame is where they differ

@@ -213,3 +213,67 @@ def test_full_config2_size_consistency(gpu_device):
     want = conv3x3(h, pack_conv3x3_weight(net.tail.weight), 3, bias=net.tail.bias)
     got = net(lr)
     assert float((got - want).abs().max() / want.abs().max()) < 1e-4
+
+
+# ------------------------------------------------------------------ collapsed x4 upsampler (conv5x5 + PixelShuffle(4))
+@pytest.mark.parametrize("N,Cin,H,W,Cout,bias", [
+    (2, 64, 40, 72, 48, True),      # the SR net's shape class: 64 features -> 3 bands x 16 sub-pixels
+    (1, 64, 17, 33, 80, True),      # 5 bands: two output-channel groups, ragged tile edges
+    (3, 10, 9, 5, 16, False),       # channel count not a multiple of the LDS chunk, image smaller than one tile
+    (1, 5, 8, 32, 32, True),
+])
+def test_conv5x5_ps4_vs_torch(N, Cin, H, W, Cout, bias, gpu_device):
+    from kmsr_amd.sr import conv5x5_ps4
+    g = torch.Generator().manual_seed(Cin * 100 + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 5, 5, generator=g) / (5 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g) if bias else None
+    lib = L.load()
+    wd = w.to(gpu_device)
+    packed = torch.empty(lib.kmsr_conv5x5_ps4_packed_weight_floats(Cin, Cout), device=gpu_device)
+    L.check(lib.kmsr_conv5x5_ps4_pack_weights_f32(L.ptr(wd), Cin, Cout, L.ptr(packed), L.current_stream()))
+    out = conv5x5_ps4(x.to(gpu_device), packed, Cout, bias=None if b is None else b.to(gpu_device))
+    ref = F.pixel_shuffle(F.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=2), 4)
+    assert tuple(out.shape) == (N, Cout // 16, 4 * H, 4 * W)
+    _check(out, ref, what="conv5x5_ps4")
+    with pytest.raises(AssertionError):     # KMSR_E_SHAPE: Cout must be a multiple of 16
+        L.check(lib.kmsr_conv5x5_ps4_fwd_f32(1, Cin, H, W, 24, L.ptr(x.to(gpu_device)), L.ptr(packed), None,
+                                             L.ptr(out), L.current_stream()))
+
+
+@pytest.mark.parametrize("colors,feats,blocks,shape", [(3, 64, 2, (2, 3, 40, 72)), (5, 32, 1, (1, 5, 18, 8)),
+                                                        (3, 64, 1, (1, 3, 64, 64))])
+def test_srnet_fused_upsampler_matches_layerwise(colors, feats, blocks, shape, gpu_device):
+    """fuse_upsampler=True (one conv5x5+PS4 launch + exact frame strips) against the layer-by-layer path and the
+    stock-torch oracle, borders included."""
+    torch.manual_seed(11)
+    ref = SRNetTorch(colors, feats, blocks, 4).eval()
+    net = SRNet(colors, feats, blocks, 4)
+    net.load_state_dict(ref.state_dict())
+    net = net.to(gpu_device).eval()
+    x = torch.rand(*shape) * 2 - 1
+    with torch.no_grad():
+        want = ref(x)
+    layerwise = net(x.to(gpu_device))
+    net.fuse_upsampler = True
+    fused = net(x.to(gpu_device))
+    scale = float(want.abs().max())
+    assert float((fused.cpu() - want).abs().max()) < 1e-4 * scale
+    assert float((fused - layerwise).abs().max()) < 2e-5 * scale
+    # the recomputed frame and the interior are both covered: compare the border ring separately
+    ring = torch.ones_like(want, dtype=torch.bool)
+    ring[:, :, 4:-4, 4:-4] = False
+    assert float((fused.cpu() - want)[ring].abs().max()) < 1e-4 * scale
+
+
+def test_srnet_fused_upsampler_follows_weight_updates(gpu_device):
+    torch.manual_seed(5)
+    net = SRNet(3, 32, 1, 4).to(gpu_device).eval()
+    net.fuse_upsampler = True
+    x = torch.rand(1, 3, 16, 16, device=gpu_device)
+    y0 = net(x)
+    with torch.no_grad():
+        net.tail.weight.mul_(2.0)
+        net.tail.bias.mul_(2.0)
+    y1 = net(x)
+    assert torch.allclose(y1, 2 * y0, rtol=1e-4, atol=1e-5)
