@@ -108,13 +108,22 @@ def conv3x3_wgrad(x, dy):
 
 class Conv3x3Function(torch.autograd.Function):
     """y = [relu](conv3x3(x, w) + b) with the HIP kernels in both directions (stride 1):
-    forward  kmsr_conv3x3_fwd_f32, backward  dx = conv3x3(g, flip-transposed w) (same kernel), dw = kmsr_conv3x3_wgrad_f32,
-    db = sum(g).  ReLU's mask is applied to the incoming gradient from the saved output."""
+    forward  kmsr_conv3x3[_wino]_fwd_f32, backward  dx = conv3x3(g, flip-transposed w) (same kernels), dw =
+    kmsr_conv3x3_wgrad_f32, db = sum(g).  ReLU's mask is applied to the incoming gradient from the saved output.
+    Forward and data gradient take the Winograd kernel where it is eligible (F->F and F->4F layers)."""
+    use_winograd = True
+
+    @staticmethod
+    def _run(x, w, bias, relu):
+        cout, cin = w.shape[0], w.shape[1]
+        if Conv3x3Function.use_winograd and winograd_eligible(cin, cout, 1, x.shape[-1]):
+            return conv3x3(x, pack_conv3x3_weight_wino(w), cout, bias=bias, relu=relu, algo="winograd")
+        return conv3x3(x, pack_conv3x3_weight(w), cout, bias=bias, relu=relu)
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
         x = x.contiguous()
-        y = conv3x3(x, pack_conv3x3_weight(weight), weight.shape[0], bias=bias, relu=relu)
+        y = Conv3x3Function._run(x, weight.detach(), bias, relu)
         ctx.relu = relu
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.has_bias = bias is not None
@@ -128,7 +137,8 @@ class Conv3x3Function(torch.autograd.Function):
             g = g * (y > 0)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = conv3x3(g, pack_conv3x3_weight(weight, transpose_flip=True), weight.shape[1])
+            # data gradient = the same convolution with w'[ci,co,u,v] = w[co,ci,2-u,2-v]
+            dx = Conv3x3Function._run(g, weight.detach().flip(2, 3).transpose(0, 1).contiguous(), None, False)
         if ctx.needs_input_grad[1]:
             dw = conv3x3_wgrad(x, g)
         if ctx.has_bias and ctx.needs_input_grad[2]:
