@@ -211,9 +211,25 @@ class DegradeSRWorkload:
             el = time.perf_counter() - t0
             if el > budget_s or n >= 16:
                 break
+        # the metric's second half, "PSNR delta vs ref": the same patch (same noise stream: seed 42, offset 0) through the
+        # HIP path and through the oracle, PSNR of each against the HR patch (declared data range R = 100, the radiance
+        # span of the synthetic tiles), and the largest relative difference of the two SR outputs
+        from kmsr_amd.sr import psnr
+        sr_cpu = one()
+        lr0 = kmsr_amd.degrade_batch(self.hr[:1], self.bank, 4, down="stride", pad="zero", normalize=False,
+                                     kernel_idx=self.kid[:1], sigma=self.sigma, noise="gaussian", seed=42, offset=0)
+        hr0 = self.hr[:1].cpu()
+        deltas = {}
+        for tag, fuse in (("layerwise", False), ("collapsed_upsampler", True)):
+            self.net.fuse_upsampler = fuse
+            sr_gpu = self.net(lr0).cpu()
+            deltas[tag] = {"psnr_delta_db": round(psnr(sr_gpu, hr0, 100.0) - psnr(sr_cpu, hr0, 100.0), 7),
+                           "max_rel_diff": float((sr_gpu - sr_cpu).abs().max() / sr_cpu.abs().max())}
+        self.net.fuse_upsampler = False
         return {"value": round(n / el, 3), "unit": "LR patches/s", "cores": cores, "kind": "port",
                 "sample": f"{n} patch(es): HR 3x1024x1024 -> LR 256^2 -> SR 1024^2, oracle C degradation + torch-CPU "
-                          f"SRNetTorch fp32, {el:.1f} s on {cores} threads"}
+                          f"SRNetTorch fp32, {el:.1f} s on {cores} threads",
+                "psnr_vs_oracle": deltas}
 
 
 class SRBf16Workload:

@@ -112,6 +112,18 @@ int kmsr_degrade_f32(const kmsr_degrade_desc* d,
                      float* lr,                  /* [N,C,h,w] contiguous                             */
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward of kmsr_degrade_f32 w.r.t. the blur kernels and noise sigmas, for the V-B configuration the reference
+ * differentiates (ContentAdaptiveDegradation.forward muti_kernel/train_gemini.py:117-138 under loss_G.backward()
+ * :219-222): down_mode STRIDE, normalize 0, pad ZERO or REPLICATE, factor <= 8, kh*kw <= 512.
+ *   dkernels[n,c,u,v] = sum_{i,j} grad_lr[n,c,i,j] * x0[n,c, f*i+u-kh/2, f*j+v-kw/2]        [N,C,kh,kw]  (or NULL)
+ *   dsigma[n,c]       = sum_{i,j} grad_lr[n,c,i,j] * eps[n,c,i,j]   (same (seed, offset) stream)  [N,C]  (or NULL)
+ * Per-SAMPLE gradients: a caller that mixed / gathered a kernel bank (kernel_idx, einsum weights) finishes the chain
+ * rule itself.  Deterministic (per-tile partial sums in the workspace, added in a fixed order).  The HR batch is read
+ * once: HBM-bound like the forward.  The gradient w.r.t. the HR image is not provided (patches are data). */
+size_t kmsr_degrade_bwd_workspace_bytes(const kmsr_degrade_desc* d);
+int kmsr_degrade_bwd_f32(const kmsr_degrade_desc* d, const float* hr, const float* grad_lr /* [N,C,h,w] */,
+                         float* dkernels, float* dsigma, void* workspace, size_t workspace_bytes, void* stream);
+
 /* eps stream only: out[p,i,j] = eps(p,i,j)  (tests; p < planes) */
 int kmsr_gaussian_eps_f32(float* out, int32_t planes, int32_t h, int32_t w, uint64_t seed, uint32_t offset,
                           void* stream);

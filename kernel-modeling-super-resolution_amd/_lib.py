@@ -56,6 +56,8 @@ SYMBOLS = {
     "kmsr_degrade_workspace_bytes": (_sz, [C.POINTER(DegradeDesc)]),
     "kmsr_degrade_uses_fast_path": (C.c_int, [C.POINTER(DegradeDesc), _vp]),
     "kmsr_degrade_f32": (C.c_int, [C.POINTER(DegradeDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kmsr_degrade_bwd_workspace_bytes": (_sz, [C.POINTER(DegradeDesc)]),
+    "kmsr_degrade_bwd_f32": (C.c_int, [C.POINTER(DegradeDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kmsr_gaussian_eps_f32": (C.c_int, [_vp, _i32, _i32, _i32, _u64, _u32, _vp]),
     "kmsr_noise_crops_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "kmsr_conv3x3_packed_weight_floats": (_sz, [_i32, _i32]),

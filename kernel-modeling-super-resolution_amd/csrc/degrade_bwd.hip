@@ -1,0 +1,206 @@
+// Backward of the fused degradation (V-B configuration: strided sampling, kernels applied as given) with respect to
+// the blur kernels and the noise sigmas -- what the MoE / KernelGAN trainers differentiate
+// (ContentAdaptiveDegradation.forward, muti_kernel/train_gemini.py:117-138; loss_G.backward() :219-222).
+//
+//   out[b,c,i,j] = sum_{u,v} K[b,c,u,v] * x0[b,c,F*i+u-ph,F*j+v-pw] + sigma[b,c] * eps[b,c,i,j]
+//   dK[b,c,u,v]  = sum_{i,j} g[b,c,i,j] * x0[b,c,F*i+u-ph,F*j+v-pw]
+//   dsigma[b,c]  = sum_{i,j} g[b,c,i,j] * eps[b,c,i,j]          (eps regenerated from the forward's Philox stream)
+//
+// Each (sample, band) plane has its own image, so this is a batched matrix-vector product: no operand reuse across
+// planes, HBM-bound (the HR batch is read exactly once, like the forward).  Workgroup = one 16x16 tile of LR pixels of
+// one plane: the HR halo tile ((16-1)F+kh rows) and the 256 upstream gradients go to LDS, thread (tap, s) accumulates
+// its tap over the LR rows i = s (mod S), S = 512 / taps pixel-splits keep all 8 waves busy (169 taps -> 507 threads);
+// per-tile partial sums go to the workspace and a second kernel adds them in a fixed order (bit-reproducible, no
+// float atomics).
+#include "kmsr_common.h"
+#include "kmsr_noise.h"
+
+#include <algorithm>
+
+namespace kmsr {
+namespace {
+
+constexpr int BT = 16;          // LR tile edge
+constexpr int BTHREADS = 512;
+
+struct BwdParams {
+    const float* hr;
+    long long sN, sC, sH;
+    const float* g;
+    float* part;           // [planes][tiles][ntaps + 1]
+    int C, H, W, h, w, F, kh, kw, ph, pw, pad_zero;
+    int tiles_x, tiles, rows, cols, pitch, S;
+    unsigned long long seed;
+    unsigned offset;
+    int want_sigma;
+};
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__global__ void __launch_bounds__(BTHREADS) degrade_bwd_kernel(BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                                   // [rows][pitch]
+    float* gs = smem + p.rows * p.pitch;                // [BT][BT]
+    float* red = gs + BT * BT;                          // [S][ntaps] + sigma scratch [64]
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x % p.tiles, plane = blockIdx.x / p.tiles;
+    const int n = plane / p.C, c = plane % p.C;
+    const int i0 = (tile / p.tiles_x) * BT, j0 = (tile % p.tiles_x) * BT;
+    const float* __restrict__ x = p.hr + n * p.sN + c * p.sC;
+    const int ntaps = p.kh * p.kw;
+
+    // ---- stage the HR halo tile (zero or replicate padding) and the gradient tile (0 outside the LR image)
+    const int y0 = i0 * p.F - p.ph, x0 = j0 * p.F - p.pw;
+    for (int e = tid; e < p.rows * p.cols; e += BTHREADS) {
+        const int r = e / p.cols, q = e - r * p.cols;
+        int gy = y0 + r, gx = x0 + q;
+        float v = 0.f;
+        if (p.pad_zero) {
+            const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const float t = x[ok ? gy * p.sH + gx : 0];
+            v = ok ? t : 0.f;
+        } else {
+            gy = min(max(gy, 0), p.H - 1);
+            gx = min(max(gx, 0), p.W - 1);
+            v = x[gy * p.sH + gx];
+        }
+        xs[r * p.pitch + q] = v;
+    }
+    const float* __restrict__ gp = p.g + (long long)plane * p.h * p.w;
+    if (tid < BT * BT) {
+        const int i = i0 + tid / BT, j = j0 + tid % BT;
+        const bool ok = i < p.h && j < p.w;
+        const float t = gp[ok ? (long long)i * p.w + j : 0];
+        gs[tid] = ok ? t : 0.f;
+    }
+    __syncthreads();
+
+    // ---- thread (tap, s): acc = sum over rows i = s (mod S), all 16 columns
+    const int s = tid / ntaps, tap = tid - s * ntaps;
+    float acc = 0.f;
+    if (s < p.S) {
+        const int u = tap / p.kw, v = tap - u * p.kw;
+        for (int i = s; i < BT; i += p.S) {
+            const float* xr = xs + (i * p.F + u) * p.pitch + v;
+            const f32x4* g4 = reinterpret_cast<const f32x4*>(gs + i * BT);
+#pragma unroll
+            for (int q = 0; q < BT / 4; ++q) {
+                const f32x4 gv = g4[q];
+                acc = fmaf(gv.x, xr[(4 * q + 0) * p.F], acc);
+                acc = fmaf(gv.y, xr[(4 * q + 1) * p.F], acc);
+                acc = fmaf(gv.z, xr[(4 * q + 2) * p.F], acc);
+                acc = fmaf(gv.w, xr[(4 * q + 3) * p.F], acc);
+            }
+        }
+        red[s * ntaps + tap] = acc;
+    }
+    // ---- dsigma partial: 64 threads, each 4 rows of one column (one Philox call yields the 4 normals of rows 4*iblk..+3)
+    float* sred = red + p.S * ntaps;
+    if (p.want_sigma && tid < 64) {
+        const int ib = tid / BT, jj = tid % BT;
+        const int i = i0 + 4 * ib, j = j0 + jj;
+        float z[4], sg = 0.f;
+        eps4(p.seed, p.offset, (unsigned)plane, (unsigned)(i >> 2), (unsigned)j, z);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sg = fmaf(gs[(4 * ib + k) * BT + jj], z[k], sg);   // gs is 0 outside the image
+        sred[tid] = sg;
+    }
+    __syncthreads();
+    float* out = p.part + ((long long)plane * p.tiles + tile) * (ntaps + 1);
+    for (int t = tid; t < ntaps; t += BTHREADS) {
+        float a = red[t];
+        for (int k = 1; k < p.S; ++k) a += red[k * ntaps + t];
+        out[t] = a;
+    }
+    if (tid == 0) {
+        float a = 0.f;
+        if (p.want_sigma)
+            for (int k = 0; k < 64; ++k) a += sred[k];
+        out[ntaps] = a;
+    }
+}
+
+// dk[plane][tap] = sum_tiles part[plane][tile][tap] (fixed order); dsigma[plane] likewise
+__global__ void degrade_bwd_reduce_kernel(const float* __restrict__ part, int tiles, int ntaps, float* __restrict__ dk,
+                                          float* __restrict__ dsigma) {
+    const int plane = blockIdx.x;
+    const float* pp = part + (long long)plane * tiles * (ntaps + 1);
+    for (int t = threadIdx.x; t <= ntaps; t += blockDim.x) {
+        float a = 0.f;
+        for (int k = 0; k < tiles; ++k) a += pp[(long long)k * (ntaps + 1) + t];
+        if (t < ntaps) {
+            if (dk) dk[(long long)plane * ntaps + t] = a;
+        } else if (dsigma) {
+            dsigma[plane] = a;
+        }
+    }
+}
+
+int check_desc(const kmsr_degrade_desc* d) {
+    if (!d) return fail(KMSR_E_BADARG, "null descriptor");
+    if (d->N <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0) return fail(KMSR_E_BADARG, "bad HR shape");
+    if (d->kh <= 0 || d->kw <= 0 || d->kh > 31 || d->kw > 31 || !(d->kh & 1) || !(d->kw & 1))
+        return fail(KMSR_E_BADARG, "kernel size must be odd and <= 31 (got %dx%d)", d->kh, d->kw);
+    if (d->down_mode != KMSR_DOWN_STRIDE || d->normalize)
+        return fail(KMSR_E_UNSUPPORTED, "degrade backward is implemented for down_mode STRIDE without normalisation (V-B)");
+    if (d->factor < 1 || d->factor > 8) return fail(KMSR_E_UNSUPPORTED, "degrade backward: factor %d not in [1, 8]", d->factor);
+    if (d->pad_mode != KMSR_PAD_ZERO && d->pad_mode != KMSR_PAD_REPLICATE) return fail(KMSR_E_BADARG, "bad pad_mode");
+    return KMSR_OK;
+}
+
+}  // namespace
+}  // namespace kmsr
+
+using namespace kmsr;
+
+extern "C" size_t kmsr_degrade_bwd_workspace_bytes(const kmsr_degrade_desc* d) {
+    if (check_desc(d) != KMSR_OK) return 0;
+    const int h = ceil_div(d->H, d->factor), w = ceil_div(d->W, d->factor);
+    const size_t tiles = (size_t)ceil_div(h, BT) * ceil_div(w, BT);
+    return (size_t)d->N * d->C * tiles * (d->kh * d->kw + 1) * sizeof(float);
+}
+
+extern "C" int kmsr_degrade_bwd_f32(const kmsr_degrade_desc* d, const float* hr, const float* grad_lr, float* dkernels,
+                                    float* dsigma, void* workspace, size_t workspace_bytes, void* stream_) {
+    const int rc = check_desc(d);
+    if (rc != KMSR_OK) return rc;
+    if (!hr || !grad_lr || !workspace || (!dkernels && !dsigma)) return fail(KMSR_E_BADARG, "null tensor pointer");
+    if (dsigma && d->noise_mode != KMSR_NOISE_GAUSSIAN)
+        return fail(KMSR_E_BADARG, "dsigma requested but the forward used no Gaussian noise");
+    if (workspace_bytes < kmsr_degrade_bwd_workspace_bytes(d))
+        return fail(KMSR_E_NOMEM, "degrade backward workspace too small: %zu < %zu", workspace_bytes,
+                    kmsr_degrade_bwd_workspace_bytes(d));
+    if (d->hr_stride_c * d->C >= (1ll << 40)) return fail(KMSR_E_UNSUPPORTED, "HR strides too large");
+    BwdParams p{};
+    p.hr = hr; p.sN = d->hr_stride_n; p.sC = d->hr_stride_c; p.sH = d->hr_stride_h;
+    p.g = grad_lr;
+    p.part = static_cast<float*>(workspace);
+    p.C = d->C; p.H = d->H; p.W = d->W; p.F = d->factor; p.kh = d->kh; p.kw = d->kw; p.ph = d->kh / 2; p.pw = d->kw / 2;
+    p.h = ceil_div(d->H, d->factor);
+    p.w = ceil_div(d->W, d->factor);
+    p.pad_zero = d->pad_mode == KMSR_PAD_ZERO;
+    p.tiles_x = ceil_div(p.w, BT);
+    p.tiles = p.tiles_x * ceil_div(p.h, BT);
+    p.rows = (BT - 1) * p.F + p.kh;
+    p.cols = (BT - 1) * p.F + p.kw;
+    p.pitch = p.cols | 1;            // odd pitch: the 13 rows of taps a wave touches fall on different banks
+    const int ntaps = p.kh * p.kw;
+    p.S = std::max(1, std::min(BT, BTHREADS / ntaps));
+    if (ntaps > BTHREADS) return fail(KMSR_E_UNSUPPORTED, "degrade backward: kernels above 22x22 taps are not implemented");
+    p.seed = d->seed; p.offset = d->offset;
+    p.want_sigma = dsigma != nullptr;
+    const size_t lds = ((size_t)p.rows * p.pitch + BT * BT + (size_t)p.S * ntaps + 64) * sizeof(float);
+    if (lds > 160 * 1024) return fail(KMSR_E_UNSUPPORTED, "degrade backward: tile does not fit LDS");
+    const long long planes = (long long)d->N * d->C;
+    const long long nblocks = planes * p.tiles;
+    if (nblocks > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "grid too large");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (lds > 64 * 1024)
+        KMSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(degrade_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    degrade_bwd_kernel<<<(int)nblocks, BTHREADS, lds, stream>>>(p);
+    KMSR_HIP_CHECK(hipGetLastError());
+    degrade_bwd_reduce_kernel<<<(int)planes, 256, 0, stream>>>(p.part, p.tiles, ntaps, dkernels, dsigma);
+    KMSR_HIP_CHECK(hipGetLastError());
+    return KMSR_OK;
+}

@@ -126,6 +126,67 @@ def degrade_batch(hr, kernels, factor, *, down="avgpool", pad="replicate", norma
     return out
 
 
+
+def degrade_backward(hr, grad_lr, ksize, factor, *, pad="zero", seed=0, offset=0, want_kernels=True, want_sigma=True):
+    """Gradients of the V-B degradation (down="stride", normalize=False) w.r.t. per-sample kernels and sigmas
+    (kmsr_degrade_bwd_f32; the chain the reference differentiates at train_gemini.py:117-138 / :219-222).
+    hr [N,C,H,W], grad_lr [N,C,ceil(H/f),ceil(W/f)], ksize (kh, kw) -> (dkernels [N,C,kh,kw] | None, dsigma [N,C] | None)."""
+    L.require_gpu()
+    lib = L.load()
+    if hr.device.type != "cuda" or hr.dtype != torch.float32 or hr.ndim != 4:
+        raise ValueError("hr must be a 4-D float32 CUDA tensor")
+    if hr.stride(3) != 1:
+        hr = hr.contiguous()
+    N, Cc, H, W = hr.shape
+    kh, kw = (ksize, ksize) if isinstance(ksize, int) else ksize
+    d = L.DegradeDesc()
+    d.N, d.C, d.H, d.W = N, Cc, H, W
+    d.hr_stride_n, d.hr_stride_c, d.hr_stride_h = hr.stride(0), hr.stride(1), hr.stride(2)
+    d.n_kernels, d.kh, d.kw, d.factor = N, int(kh), int(kw), int(factor)
+    d.down_mode, d.normalize = L.DOWN_STRIDE, 0
+    d.pad_mode = {"replicate": L.PAD_REPLICATE, "zero": L.PAD_ZERO}[pad]
+    d.noise_mode = L.NOISE_GAUSSIAN if want_sigma else L.NOISE_NONE
+    d.seed, d.offset = int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 32 - 1)
+    h, w = -(-H // int(factor)), -(-W // int(factor))
+    grad_lr = grad_lr.to(torch.float32).contiguous()
+    assert grad_lr.is_cuda and tuple(grad_lr.shape) == (N, Cc, h, w), \
+        f"grad_lr {tuple(grad_lr.shape)} != LR shape {(N, Cc, h, w)}"
+    nbytes = lib.kmsr_degrade_bwd_workspace_bytes(d)
+    ws = torch.empty(max(nbytes, 4) // 4, device=hr.device, dtype=torch.float32)   # nbytes == 0: the call reports why
+    dk = torch.empty((N, Cc, kh, kw), device=hr.device, dtype=torch.float32) if want_kernels else None
+    ds = torch.empty((N, Cc), device=hr.device, dtype=torch.float32) if want_sigma else None
+    with torch.cuda.device(hr.device):
+        L.check(lib.kmsr_degrade_bwd_f32(d, L.ptr(hr), L.ptr(grad_lr), L.ptr(dk), L.ptr(ds), L.ptr(ws), nbytes,
+                                         L.current_stream()))
+    return dk, ds
+
+
+class DegradeFunction(torch.autograd.Function):
+    """Differentiable V-B degradation: out = blur_stride(x, kernels) + sigma * eps, HIP kernels in both directions.
+    kernels [N,C,kh,kw] and sigma [N,C] are per sample (mix / gather a bank before calling so autograd finishes the
+    chain rule); x is treated as data (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, kernels, sigma, factor, pad, seed, offset):
+        out = degrade_batch(x, kernels.detach(), factor, down="stride", pad=pad, normalize=False,
+                            sigma=None if sigma is None else sigma.detach(),
+                            noise="none" if sigma is None else "gaussian", seed=seed, offset=offset)
+        ctx.save_for_backward(x)
+        ctx.meta = (tuple(kernels.shape[2:]), factor, pad, seed, offset, sigma is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        ksize, factor, pad, seed, offset, has_sigma = ctx.meta
+        want_k, want_s = ctx.needs_input_grad[1], has_sigma and ctx.needs_input_grad[2]
+        dk = ds = None
+        if want_k or want_s:
+            dk, ds = degrade_backward(x, g, ksize, factor, pad=pad, seed=seed, offset=offset, want_kernels=want_k,
+                                      want_sigma=want_s)
+        return None, dk, ds, None, None, None, None
+
+
 def workspace_for(hr_shape, kernels_shape, factor, down="avgpool", device=None):
     """A workspace tensor sized for degrade_batch on this geometry."""
     lib = L.load()

@@ -6,18 +6,21 @@ reference's `moe_model.pth` loads unchanged) and the same forward contract:
 
     out, weights, valid_kernels = model(x, temp=1.0, hard=False)       # train_gemini.py:88-140
 
-Forward is inference-only here (no autograd through the HIP kernels yet: the GAN trainer that needs it is SURVEY 8f
-N1, "next") and runs on the GPU only.  BatchNorm is applied in EVAL mode with the running statistics of the
-checkpoint, folded into the stride-2 convs (SURVEY 8a': the deployment mode; the reference's trainer never calls
-.eval()).
+Runs on the GPU only.  eval() mode (or torch.no_grad()): inference -- BatchNorm uses the running statistics of the
+checkpoint, folded into the stride-2 convs (SURVEY 8a': the deployment mode).  train() mode with grad enabled: the
+differentiable path the reference's trainer runs (train_gemini.py:169-232 never calls .eval(), so BatchNorm uses batch
+statistics there): selector convs through Conv3x3Function (HIP forward / dgrad / wgrad), degradation through
+DegradeFunction (HIP forward + kmsr_degrade_bwd_f32 for d/d kernel and d/d sigma); softmax / softplus / Gumbel /
+einsum over the tiny banks stay torch ops so autograd finishes the chain rule into kernel_bank, sigma_bank and the
+selector.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib as L
-from .degradation import degrade_batch
-from .sr import conv3x3, pack_conv3x3_weight
+from .degradation import DegradeFunction, degrade_batch
+from .sr import Conv3x3Function, conv3x3, pack_conv3x3_weight
 
 
 class SelectorNet(nn.Module):
@@ -49,11 +52,28 @@ class SelectorNet(nn.Module):
             self._folded = (key, layers)
         return self._folded[1]
 
-    @torch.no_grad()
     def forward(self, x):
         L.require_gpu()
         if not x.is_cuda:
             raise L.KmsrError("SelectorNet.forward runs on the GPU only (no CPU fallback)")
+        if torch.is_grad_enabled() and self.training:
+            return self._forward_train(x)
+        with torch.no_grad():
+            return self._forward_infer(x)
+
+    def _forward_train(self, x):
+        """Differentiable path, BatchNorm as the module's mode says (batch statistics in train()).  A stride-2 pad-1
+        conv equals the stride-1 conv sampled at even positions, so the stride-1 HIP forward / dgrad / wgrad kernels
+        serve it (4x the minimum work on a net that is ~1 % of a step)."""
+        h = x
+        for ci, bi in ((0, 1), (3, 4), (6, 7)):
+            conv, bn = self.features[ci], self.features[bi]
+            h = Conv3x3Function.apply(h, conv.weight, conv.bias, False)[:, :, ::2, ::2]
+            h = F.relu(bn(h))
+        feat = h.mean(dim=(2, 3))
+        return self.classifier(feat)
+
+    def _forward_infer(self, x):
         h = x
         for pw, b, cout in self._fold():
             h = conv3x3(h, pw, cout, bias=b, relu=True, stride=2)
@@ -89,10 +109,30 @@ class ContentAdaptiveDegradation(nn.Module):
         """:82-86"""
         return F.softplus(self.sigma_bank)
 
-    @torch.no_grad()
     def forward(self, x, temp=1.0, hard=False, weights=None):
         """x [B,C,H,W] CUDA float32.  Returns (out [B,C,ceil(H/4),ceil(W/4)], weights [B,K], valid_kernels [K,C,k,k]).
         `weights` may be passed to bypass the Gumbel draw (tests / a uniformly random kernel per sample)."""
+        if torch.is_grad_enabled() and self.training:
+            return self._forward_train(x, temp, hard, weights)
+        with torch.no_grad():
+            return self._forward_infer(x, temp, hard, weights)
+
+    def _forward_train(self, x, temp, hard, weights):
+        """train_gemini.py:88-140 with autograd: every line is the reference's; only the grouped conv + ::4 + noise
+        (:117-138) is the fused HIP kernel pair."""
+        if weights is None:
+            logits = self.selector(x)                                               # :98
+            weights = F.gumbel_softmax(logits, tau=temp, hard=hard, dim=1)          # :103
+        valid_kernels = self.get_effective_kernels()                                # :107
+        valid_sigmas = self.get_effective_sigmas()                                  # :108
+        batch_kernels = torch.einsum('bk, kchw -> bchw', weights, valid_kernels)    # :112
+        batch_sigmas = torch.einsum('bk, kc -> bc', weights, valid_sigmas)          # :115
+        out = DegradeFunction.apply(x.detach(), batch_kernels, batch_sigmas, self.downscale, "zero", self.noise_seed,
+                                    self.noise_offset)
+        self.noise_offset += 1
+        return out, weights, valid_kernels
+
+    def _forward_infer(self, x, temp, hard, weights):
         B, C, H, W = x.shape
         if weights is None:
             logits = self.selector(x)                                               # :98

@@ -97,6 +97,34 @@ def vb_blur_stride(x, kernels, f=4):
     return out
 
 
+def vb_backward(x, g, ksize=13, f=4, pad="zero"):
+    """d/dK of vb_blur_stride (train_gemini.py:117-134 under autograd): per (sample, band) plane
+    dK[u,v] = sum_{i,j} g[i,j] * x0[f*i+u-p, f*j+v-p]  -- float64 accumulation, returned as float64 [N,C,k,k].
+    Test infrastructure only."""
+    x = np.asarray(x, np.float64)
+    g = np.asarray(g, np.float64)
+    N, C, H, W = x.shape
+    p = ksize // 2
+    h, w = -(-H // f), -(-W // f)
+    assert g.shape == (N, C, h, w)
+    ext = (h - 1) * f + ksize, (w - 1) * f + ksize            # padded extent the taps can reach
+    xp = np.pad(x, ((0, 0), (0, 0), (p, max(ext[0] - H - p, 0)), (p, max(ext[1] - W - p, 0))),
+                mode="constant" if pad == "zero" else "edge")
+    dk = np.empty((N, C, ksize, ksize), np.float64)
+    for u in range(ksize):
+        for v in range(ksize):
+            dk[:, :, u, v] = (g * xp[:, :, u:u + f * h:f, v:v + f * w:f]).sum(axis=(2, 3))
+    return dk
+
+
+def vb_backward_sigma(g, seed, offset=0):
+    """d/dsigma of add_gaussian_noise: sum_{i,j} g * eps with the same counter-based stream -> float64 [N,C]."""
+    g = np.asarray(g, np.float64)
+    N, C, h, w = g.shape
+    eps = gaussian_eps(N * C, h, w, seed, offset).reshape(N, C, h, w).astype(np.float64)
+    return (g * eps).sum(axis=(2, 3))
+
+
 def philox_u32(seed, c0, c1, c2, c3):
     out = (C.c_uint32 * 4)()
     lib().oracle_philox_u32(C.c_uint64(seed), C.c_uint32(c0), C.c_uint32(c1), C.c_uint32(c2), C.c_uint32(c3), out)

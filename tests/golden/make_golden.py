@@ -279,7 +279,7 @@ def main():
             print(f"{f:28s} {os.path.getsize(os.path.join(OUT, f)) / 1024:9.1f} KiB")
 
 
-if __name__ == "__main__" and "--patch-cutter" not in sys.argv:
+if __name__ == "__main__" and "--patch-cutter" not in sys.argv and "--moe-backward" not in sys.argv:
     main()
 
 
@@ -327,5 +327,49 @@ def make_patch_cutter_golden():
     print({k: (v.tolist() if v.size <= 3 else v.shape) for k, v in out.items() if k.endswith("total_kept") or k == "masked_nan_count"})
 
 
-if __name__ == "__main__":
+def make_moe_backward_golden():
+    """Gradients the reference's MoE trainer computes (train_gemini.py:169-232: loss.backward() through
+    ContentAdaptiveDegradation.forward :88-140 and SelectorNet :14-39 in TRAIN mode -- the trainer never calls .eval()).
+    Inputs are regenerated from seeds by the test; only the reference's outputs are stored.
+      d kernel_bank of  L = sum(out * G)   (independent of the forward's randn noise; weights = the forward's own Gumbel draw)
+      train-mode selector logits and d conv0.weight / d classifier.weight of  L = sum(logits * Gl)"""
+    m = _import_reference()
+    model = m["gemini"].ContentAdaptiveDegradation(n_kernels=10, n_channels=5, kernel_size=13)
+    sd = torch.load(f"{REF}/moe_kernels/moe_model.pth", weights_only=True, map_location="cpu")
+    model.load_state_dict(sd)
+    model.train()
+    B, C, H, W = 3, 5, 40, 44
+    x = landsat_like((B, C, H, W), 31)
+    G = torch.randn(B, C, 10, 11, generator=torch.Generator().manual_seed(32))
+    Gl = torch.randn(B, 10, generator=torch.Generator().manual_seed(33))
+    out = {}
+    torch.manual_seed(5)
+    o, weights, vk = model(x, temp=2.0, hard=False)
+    model.zero_grad()
+    (o * G).sum().backward()
+    out["weights"] = weights.detach().numpy()
+    out["d_kernel_bank"] = model.kernel_bank.grad.clone().numpy()
+    # selector alone, fresh copy of the checkpoint (the forward above updated the BN running stats)
+    sel = m["gemini"].SelectorNet(in_ch=5, num_classes=10)
+    sel.load_state_dict({k[len("selector."):]: v for k, v in sd.items() if k.startswith("selector.")})
+    sel.train()
+    logits = sel(x)
+    (logits * Gl).sum().backward()
+    out["sel_train_logits"] = logits.detach().numpy()
+    out["sel_d_conv0_w"] = sel.features[0].weight.grad.numpy()
+    out["sel_d_conv6_w_sum"] = np.array([sel.features[6].weight.grad.double().sum().item(),
+                                         sel.features[6].weight.grad.double().abs().sum().item()])
+    out["sel_d_cls_w"] = sel.classifier.weight.grad.numpy()
+    out["sel_running_mean1"] = sel.features[1].running_mean.numpy()
+    out["meta"] = np.array([B, C, H, W, 31, 32, 33], np.int64)
+    out["note"] = np.array("train_gemini.py:88-140,169-232; x=landsat_like((3,5,40,44),31), G=randn(seed 32) [3,5,10,11], "
+                           "Gl=randn(seed 33) [3,10], moe_model.pth, train mode, temp=2.0")
+    np.savez_compressed(os.path.join(OUT, "moe_backward.npz"), **out)
+    print({k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__" and "--moe-backward" in sys.argv:
+    make_moe_backward_golden()
+elif __name__ == "__main__":
     make_patch_cutter_golden()
+    make_moe_backward_golden()

@@ -100,3 +100,103 @@ def test_noise_estimator(gpu_device):
     assert_close(noisy.cpu().numpy(), want, rtol=1e-6, atol=2e-6, what="noise estimator")
     ne2 = kmsr_amd.NoiseEstimator(channels=5, init_sigma=5.0, sigma_max=0.2)
     assert float(torch.clamp(torch.exp(ne2.log_sigma.detach()), 1e-5, 0.2).max()) == pytest.approx(0.2)
+
+
+# ------------------------------------------------------------------ backward (what the MoE trainer differentiates)
+MB = golden("moe_backward.npz")
+
+
+@pytest.mark.parametrize("shape,k,f,pad", [((3, 5, 40, 44), 13, 4, "zero"), ((2, 3, 67, 129), 13, 4, "replicate"),
+                                           ((2, 2, 33, 70), 7, 2, "zero"), ((1, 5, 32, 32), 1, 1, "zero"),
+                                           ((1, 1, 300, 260), 13, 4, "zero")])
+def test_degrade_backward_vs_oracle(shape, k, f, pad, gpu_device):
+    """kmsr_degrade_bwd_f32 == the float64 restatement (which test_oracle_golden pins to the reference's autograd)."""
+    from kmsr_amd.degradation import degrade_backward
+    N, C, H, W = shape
+    x = landsat_like(shape, 40)
+    g = torch.randn(N, C, -(-H // f), -(-W // f), generator=torch.Generator().manual_seed(41))
+    dk, ds = degrade_backward(torch.from_numpy(x).cuda(), g.cuda(), k, f, pad=pad, seed=9, offset=3)
+    want = oracle.vb_backward(x, g.numpy(), k, f, pad)
+    assert_close(dk.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * np.abs(want).max(), what="dK")
+    want_s = oracle.vb_backward_sigma(g.numpy(), seed=9, offset=3)
+    assert_close(ds.cpu().numpy(), want_s, rtol=1e-4, atol=1e-5 * np.abs(want_s).max() + 1e-4, what="dsigma")
+    # bit-reproducible: fixed-order reduction, no float atomics
+    dk2, ds2 = degrade_backward(torch.from_numpy(x).cuda(), g.cuda(), k, f, pad=pad, seed=9, offset=3)
+    assert torch.equal(dk, dk2) and torch.equal(ds, ds2)
+
+
+def test_degrade_backward_errors(gpu_device):
+    from kmsr_amd.degradation import degrade_backward
+    x = torch.rand(1, 2, 16, 16, device=gpu_device)
+    with pytest.raises(AssertionError):
+        degrade_backward(x, torch.rand(1, 2, 5, 4, device=gpu_device), 13, 4)          # grad shape != LR shape
+    with pytest.raises(NotImplementedError):
+        degrade_backward(x, torch.rand(1, 2, 1, 1, device=gpu_device), 13, 16)          # factor outside [1, 8]
+
+
+def test_moe_backward_matches_reference(gpu_device):
+    """train() mode, grad enabled: d kernel_bank of L = sum(out * G) equals the reference's own autograd result
+    (fixture moe_backward.npz); d sigma_bank equals the chain rule over the oracle's noise stream."""
+    B, C, H, W, sx, sg, _ = (int(v) for v in MB["meta"])
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in golden("moe_model_state.npz").items()}
+    m = kmsr_amd.ContentAdaptiveDegradation(n_kernels=10, n_channels=5, kernel_size=13)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    m.noise_seed, m.noise_offset = 77, 5
+    x = torch.from_numpy(landsat_like((B, C, H, W), sx)).cuda()
+    G = torch.randn(B, C, -(-H // 4), -(-W // 4), generator=torch.Generator().manual_seed(sg))
+    w = torch.from_numpy(MB["weights"]).cuda()
+    out, w_out, vk = m(x, temp=2.0, hard=False, weights=w)
+    assert out.requires_grad and m.noise_offset == 6
+    (out * G.cuda()).sum().backward()
+    ref = MB["d_kernel_bank"]
+    assert_close(m.kernel_bank.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max(), what="d kernel_bank")
+    ds = torch.from_numpy(oracle.vb_backward_sigma(G.numpy(), seed=77, offset=5))                  # [B,C]
+    sb = sd["sigma_bank"].double().requires_grad_(True)
+    (torch.einsum("bk,kc->bc", torch.from_numpy(MB["weights"]).double(), torch.nn.functional.softplus(sb)) * ds).sum().backward()
+    assert_close(m.sigma_bank.grad.cpu().numpy(), sb.grad.numpy(), rtol=1e-4, atol=1e-4, what="d sigma_bank")
+    # the forward value of the differentiable path is the inference path's (same kernels, same noise stream)
+    m.eval()
+    m.noise_offset = 5
+    out_inf, _, _ = m(x, weights=w)
+    assert_close(out.detach().cpu().numpy(), out_inf.cpu().numpy(), rtol=1e-5, atol=1e-4, what="train vs infer forward")
+
+
+def test_selector_train_mode_matches_reference(gpu_device):
+    """SelectorNet in TRAIN mode (batch-statistics BatchNorm, as the reference's trainer runs it): logits and the
+    gradients of L = sum(logits * Gl) through the stride-1 HIP conv + subsample formulation == the reference's."""
+    B, C, H, W, sx, _, sgl = (int(v) for v in MB["meta"])
+    sd = {k[len("selector."):]: torch.from_numpy(np.asarray(v)) for k, v in golden("moe_model_state.npz").items()
+          if k.startswith("selector.")}
+    sel = kmsr_amd.SelectorNet(in_ch=5, num_classes=10)
+    sel.load_state_dict(sd)
+    sel = sel.cuda().train()
+    x = torch.from_numpy(landsat_like((B, C, H, W), sx)).cuda()
+    Gl = torch.randn(B, 10, generator=torch.Generator().manual_seed(sgl)).cuda()
+    logits = sel(x)
+    (logits * Gl).sum().backward()
+    assert_close(logits.detach().cpu().numpy(), MB["sel_train_logits"], rtol=1e-3, atol=1e-3, what="train-mode logits")
+    g0 = sel.features[0].weight.grad.cpu().numpy()
+    assert_close(g0, MB["sel_d_conv0_w"], rtol=2e-3, atol=2e-3 * np.abs(MB["sel_d_conv0_w"]).max(), what="d conv0.weight")
+    gc = sel.classifier.weight.grad.cpu().numpy()
+    assert_close(gc, MB["sel_d_cls_w"], rtol=1e-3, atol=1e-3 * np.abs(MB["sel_d_cls_w"]).max(), what="d classifier.weight")
+    g6 = sel.features[6].weight.grad.double()
+    assert abs(float(g6.abs().sum()) - MB["sel_d_conv6_w_sum"][1]) < 2e-3 * MB["sel_d_conv6_w_sum"][1]
+    assert_close(sel.features[1].running_mean.cpu().numpy(), MB["sel_running_mean1"], rtol=1e-4, atol=1e-4,
+                 what="BN running mean after one train-mode forward")
+
+
+def test_degrade_backward_adjoint_identity_full_size(gpu_device):
+    """Config-3 shape (HR [32,5,1024,1024]): <g, A_x(K)> == <A_x^T(g), K> -- a size-independent check of the
+    backward against the forward kernel at the full batch."""
+    from kmsr_amd.degradation import degrade_backward
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand(32, 5, 1024, 1024, device=gpu_device, generator=gen) * 80 + 20
+    K = torch.rand(32, 5, 13, 13, device=gpu_device, generator=gen) - 0.3
+    g = torch.randn(32, 5, 256, 256, device=gpu_device, generator=gen)
+    out = kmsr_amd.degrade_batch(x, K, 4, down="stride", pad="zero", normalize=False)
+    dk, _ = degrade_backward(x, g, 13, 4, want_sigma=False)
+    lhs = (out.double() * g.double()).sum(dim=(2, 3))
+    rhs = (dk.double() * K.double()).sum(dim=(2, 3))
+    scale = (out.double().abs() * g.double().abs()).sum(dim=(2, 3))
+    assert float(((lhs - rhs).abs() / scale).max()) < 1e-5

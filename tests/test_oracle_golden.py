@@ -200,3 +200,21 @@ def test_load_kernel_semantics_fixture_is_consistent():
     lk = golden("load_kernel.npz")
     assert_close(lk["batch_in"].astype(np.float32).mean(axis=0), lk["batch_out"], rtol=1e-6)
     assert lk["k2d_out_c31"].shape == (1, 13, 13) and lk["k2d_out_c30"].shape == (13, 13)
+
+
+def test_vb_backward_matches_reference_autograd():
+    """oracle.vb_backward (per-sample dK) chained through einsum + softmax in float64 == the reference's own
+    kernel_bank.grad for L = sum(out * G) (train_gemini.py:88-140 under backward; fixture moe_backward.npz)."""
+    import torch
+    MB = golden("moe_backward.npz")
+    B, C, H, W, sx, sg, _ = (int(v) for v in MB["meta"])
+    x = landsat_like((B, C, H, W), sx)
+    G = torch.randn(B, C, -(-H // 4), -(-W // 4), generator=torch.Generator().manual_seed(sg)).numpy()
+    dk = torch.from_numpy(oracle.vb_backward(x, G, 13, 4, "zero"))                    # [B,C,13,13]
+    bank = torch.from_numpy(np.asarray(golden("moe_model_state.npz")["kernel_bank"])).double().requires_grad_(True)
+    vk = torch.softmax(bank.view(10, 5, -1), dim=-1).view(10, 5, 13, 13)
+    bk = torch.einsum("bk,kchw->bchw", torch.from_numpy(MB["weights"]).double(), vk)
+    (bk * dk).sum().backward()
+    assert_close(bank.grad.numpy(), MB["d_kernel_bank"], rtol=2e-4, atol=1e-6 * np.abs(MB["d_kernel_bank"]).max(),
+                 what="d kernel_bank")
+
