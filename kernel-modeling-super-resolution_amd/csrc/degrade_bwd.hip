@@ -7,11 +7,13 @@
 //   dsigma[b,c]  = sum_{i,j} g[b,c,i,j] * eps[b,c,i,j]          (eps regenerated from the forward's Philox stream)
 //
 // Each (sample, band) plane has its own image, so this is a batched matrix-vector product: no operand reuse across
-// planes, HBM-bound (the HR batch is read exactly once, like the forward).  Workgroup = one 16x16 tile of LR pixels of
-// one plane: the HR halo tile ((16-1)F+kh rows) and the 256 upstream gradients go to LDS, thread (tap, s) accumulates
-// its tap over the LR rows i = s (mod S), S = 512 / taps pixel-splits keep all 8 waves busy (169 taps -> 507 threads);
-// per-tile partial sums go to the workspace and a second kernel adds them in a fixed order (bit-reproducible, no
-// float atomics).
+// planes, HBM-bound in principle (the HR batch is read once, like the forward).  Workgroup = one 16x16 tile of LR pixels
+// of one plane: the HR halo tile ((16-1)F+kh rows) and the 256 upstream gradients go to LDS, threads accumulate taps
+// over the tile (generic kernel: one tap per thread; V-B kernel below: 4 taps per thread, register blocked); per-tile
+// partial sums go to the workspace and a second kernel adds them in a fixed order (bit-reproducible, no float atomics).
+// Measured at the config-3 batch (HR [32,5,1024,1024]): 0.46 ms = 1.5 TB/s algorithmic (0.19 of HBM peak), 0.55 ms with
+// dsigma -- bounded by the tile fill's index arithmetic and the per-tile barriers, not by HBM; a strip-persistent
+// variant with register prefetch was slower (0.59 ms: 128+ VGPRs, 2 workgroups per CU).
 #include "kmsr_common.h"
 #include "kmsr_noise.h"
 
@@ -37,34 +39,60 @@ struct BwdParams {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-__global__ void __launch_bounds__(BTHREADS) degrade_bwd_kernel(BwdParams p) {
+// TF/TK > 0: factor and (square) kernel size are compile-time constants (V-B: 4, 13), so the index arithmetic of the
+// tile fill and of the tap loop needs no runtime divisions; TF = TK = 0: generic.
+template <int TF, int TK>
+__global__ void __launch_bounds__(BTHREADS) degrade_bwd_kernel(BwdParams pr) {
+    struct Geo {
+        const BwdParams& q;
+        __device__ int F() const { return TF ? TF : q.F; }
+        __device__ int kh() const { return TK ? TK : q.kh; }
+        __device__ int kw() const { return TK ? TK : q.kw; }
+        __device__ int rows() const { return TK ? (BT - 1) * TF + TK : q.rows; }
+        __device__ int cols() const { return TK ? (BT - 1) * TF + TK : q.cols; }
+        __device__ int pitch() const { return TK ? (((BT - 1) * TF + TK) | 1) : q.pitch; }
+        __device__ int S() const { return TK ? (BTHREADS / (TK * TK) < BT ? BTHREADS / (TK * TK) : BT) : q.S; }
+    };
+    const BwdParams& p = pr;
+    const Geo G{pr};
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                                   // [rows][pitch]
-    float* gs = smem + p.rows * p.pitch;                // [BT][BT]
+    float* gs = smem + G.rows() * G.pitch();                // [BT][BT]
     float* red = gs + BT * BT;                          // [S][ntaps] + sigma scratch [64]
     const int tid = threadIdx.x;
     const int tile = blockIdx.x % p.tiles, plane = blockIdx.x / p.tiles;
     const int n = plane / p.C, c = plane % p.C;
     const int i0 = (tile / p.tiles_x) * BT, j0 = (tile % p.tiles_x) * BT;
     const float* __restrict__ x = p.hr + n * p.sN + c * p.sC;
-    const int ntaps = p.kh * p.kw;
+    const int ntaps = G.kh() * G.kw();
 
     // ---- stage the HR halo tile (zero or replicate padding) and the gradient tile (0 outside the LR image)
-    const int y0 = i0 * p.F - p.ph, x0 = j0 * p.F - p.pw;
-    for (int e = tid; e < p.rows * p.cols; e += BTHREADS) {
-        const int r = e / p.cols, q = e - r * p.cols;
+    const int y0 = i0 * G.F() - G.kh() / 2, x0 = j0 * G.F() - G.kw() / 2;
+    auto fetch = [&](int e) -> float {
+        const int r = e / G.cols(), q = e - r * G.cols();
         int gy = y0 + r, gx = x0 + q;
-        float v = 0.f;
         if (p.pad_zero) {
-            const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            const float t = x[ok ? gy * p.sH + gx : 0];
-            v = ok ? t : 0.f;
-        } else {
-            gy = min(max(gy, 0), p.H - 1);
-            gx = min(max(gx, 0), p.W - 1);
-            v = x[gy * p.sH + gx];
+            const bool ok = e < G.rows() * G.cols() && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const float t = x[ok ? gy * p.sH + gx : 0];      // safe address + select: loads stay back to back
+            return ok ? t : 0.f;
         }
-        xs[r * p.pitch + q] = v;
+        gy = min(max(gy, 0), p.H - 1);
+        gx = min(max(gx, 0), p.W - 1);
+        return x[gy * p.sH + gx];
+    };
+    auto put = [&](int e, float v) {
+        const int r = e / G.cols(), q = e - r * G.cols();
+        if (e < G.rows() * G.cols()) xs[r * G.pitch() + q] = v;
+    };
+    if constexpr (TK > 0) {
+        constexpr int NE = ((BT - 1) * TF + TK) * ((BT - 1) * TF + TK), NT = (NE + BTHREADS - 1) / BTHREADS;
+        float v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v[t] = fetch(tid + t * BTHREADS);      // all loads in flight before the first store
+#pragma unroll
+        for (int t = 0; t < NT; ++t) put(tid + t * BTHREADS, v[t]);
+    } else {
+        for (int e = tid; e < G.rows() * G.cols(); e += BTHREADS) put(e, fetch(e));
     }
     const float* __restrict__ gp = p.g + (long long)plane * p.h * p.w;
     if (tid < BT * BT) {
@@ -78,24 +106,25 @@ __global__ void __launch_bounds__(BTHREADS) degrade_bwd_kernel(BwdParams p) {
     // ---- thread (tap, s): acc = sum over rows i = s (mod S), all 16 columns
     const int s = tid / ntaps, tap = tid - s * ntaps;
     float acc = 0.f;
-    if (s < p.S) {
-        const int u = tap / p.kw, v = tap - u * p.kw;
-        for (int i = s; i < BT; i += p.S) {
-            const float* xr = xs + (i * p.F + u) * p.pitch + v;
+    if (s < G.S()) {
+        const int u = tap / G.kw(), v = tap - u * G.kw();
+#pragma unroll 2
+        for (int i = s; i < BT; i += G.S()) {
+            const float* xr = xs + (i * G.F() + u) * G.pitch() + v;
             const f32x4* g4 = reinterpret_cast<const f32x4*>(gs + i * BT);
 #pragma unroll
             for (int q = 0; q < BT / 4; ++q) {
                 const f32x4 gv = g4[q];
-                acc = fmaf(gv.x, xr[(4 * q + 0) * p.F], acc);
-                acc = fmaf(gv.y, xr[(4 * q + 1) * p.F], acc);
-                acc = fmaf(gv.z, xr[(4 * q + 2) * p.F], acc);
-                acc = fmaf(gv.w, xr[(4 * q + 3) * p.F], acc);
+                acc = fmaf(gv.x, xr[(4 * q + 0) * G.F()], acc);
+                acc = fmaf(gv.y, xr[(4 * q + 1) * G.F()], acc);
+                acc = fmaf(gv.z, xr[(4 * q + 2) * G.F()], acc);
+                acc = fmaf(gv.w, xr[(4 * q + 3) * G.F()], acc);
             }
         }
         red[s * ntaps + tap] = acc;
     }
     // ---- dsigma partial: 64 threads, each 4 rows of one column (one Philox call yields the 4 normals of rows 4*iblk..+3)
-    float* sred = red + p.S * ntaps;
+    float* sred = red + G.S() * ntaps;
     if (p.want_sigma && tid < 64) {
         const int ib = tid / BT, jj = tid % BT;
         const int i = i0 + 4 * ib, j = j0 + jj;
@@ -109,7 +138,7 @@ __global__ void __launch_bounds__(BTHREADS) degrade_bwd_kernel(BwdParams p) {
     float* out = p.part + ((long long)plane * p.tiles + tile) * (ntaps + 1);
     for (int t = tid; t < ntaps; t += BTHREADS) {
         float a = red[t];
-        for (int k = 1; k < p.S; ++k) a += red[k * ntaps + t];
+        for (int k = 1; k < G.S(); ++k) a += red[k * ntaps + t];
         out[t] = a;
     }
     if (tid == 0) {
@@ -120,18 +149,136 @@ __global__ void __launch_bounds__(BTHREADS) degrade_bwd_kernel(BwdParams p) {
     }
 }
 
-// dk[plane][tap] = sum_tiles part[plane][tile][tap] (fixed order); dsigma[plane] likewise
+// ------------------------------------------------------------------------------------------------
+// V-B specialisation (factor 4, 13x13 taps): register-blocked tap loop.  Taps v, v+4, v+8, v+12 of one kernel row read
+// the SAME HR samples at neighbouring LR columns (x[4j + v + 4t] = x[4(j+t) + v]), so thread (s, u, v mod 4) loads one
+// strided run of 19 samples and 16 gradients per LR row and feeds 4 accumulators: 23 LDS reads per 64 FMAs instead of
+// 80 per 64.  s = 8 row splits (rows s, s+8); 8 x 13 x 4 = 416 of 512 threads take part in the tap loop; the last
+// wave regenerates the noise for the sigma gradient meanwhile.
+// ------------------------------------------------------------------------------------------------
+constexpr int VB_F = 4, VB_K = 13, VB_ROWS = (BT - 1) * VB_F + VB_K, VB_PITCH = VB_ROWS;   // 73 (odd)
+constexpr int VB_S = 8, VB_TAPS = VB_K * VB_K;
+constexpr int VB_XS = VB_ROWS * VB_PITCH + 8;      // + slack: the 19th sample of the v mod 4 > 0 threads is read, not used
+
+__global__ void __launch_bounds__(BTHREADS) degrade_bwd_vb_kernel(BwdParams p) {
+    __shared__ __attribute__((aligned(16))) float xs[VB_XS];
+    __shared__ __attribute__((aligned(16))) float gs[BT * BT];
+    __shared__ float red[VB_S * VB_TAPS + 64];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x % p.tiles, plane = blockIdx.x / p.tiles;
+    const int n = plane / p.C, c = plane % p.C;
+    const int i0 = (tile / p.tiles_x) * BT, j0 = (tile % p.tiles_x) * BT;
+    const float* __restrict__ x = p.hr + n * p.sN + c * p.sC;
+    const int y0 = i0 * VB_F - VB_K / 2, x0 = j0 * VB_F - VB_K / 2;
+
+    constexpr int NE = VB_ROWS * VB_ROWS, NT = (NE + BTHREADS - 1) / BTHREADS;
+    float v[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {              // all loads in flight before the first LDS store
+        const int e = tid + t * BTHREADS;
+        const int r = e / VB_ROWS, q = e - r * VB_ROWS;
+        int gy = y0 + r, gx = x0 + q;
+        if (p.pad_zero) {
+            const bool ok = e < NE && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const float tv = x[ok ? gy * p.sH + gx : 0];
+            v[t] = ok ? tv : 0.f;
+        } else {
+            gy = min(max(gy, 0), p.H - 1);
+            gx = min(max(gx, 0), p.W - 1);
+            v[t] = x[gy * p.sH + gx];
+        }
+    }
+    const float* __restrict__ gp = p.g + (long long)plane * p.h * p.w;
+    float gv = 0.f;
+    if (tid < BT * BT) {
+        const int i = i0 + tid / BT, j = j0 + tid % BT;
+        const bool ok = i < p.h && j < p.w;
+        const float t = gp[ok ? (long long)i * p.w + j : 0];
+        gv = ok ? t : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int e = tid + t * BTHREADS;
+        if (e < NE) xs[e] = v[t];               // pitch == row length: the tile is stored densely
+    }
+    if (tid < BT * BT) gs[tid] = gv;
+    if (tid < 8) xs[NE + tid] = 0.f;
+    __syncthreads();
+
+    const int vm = tid & 3, u = (tid >> 2) % VB_K, s = tid / (4 * VB_K);
+    if (s < VB_S) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rr = 0; rr < BT / VB_S; ++rr) {
+            const int i = s + rr * VB_S;
+            const float* xr = xs + (i * VB_F + u) * VB_PITCH + vm;
+            float xv[BT + 3];
+#pragma unroll
+            for (int j = 0; j < BT + 3; ++j) xv[j] = xr[VB_F * j];
+            const f32x4* g4 = reinterpret_cast<const f32x4*>(gs + i * BT);
+#pragma unroll
+            for (int q = 0; q < BT / 4; ++q) {
+                const f32x4 gq = g4[q];
+                const float gj[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = fmaf(gj[k], xv[4 * q + k + t], acc[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int vv = vm + 4 * t;
+            if (vv < VB_K) red[s * VB_TAPS + u * VB_K + vv] = acc[t];
+        }
+    }
+    float* sred = red + VB_S * VB_TAPS;
+    if (p.want_sigma && tid >= 448) {           // the last wave is idle in the tap loop: it owns the sigma partial
+        const int l = tid - 448, ib = l / BT, jj = l % BT;
+        const int i = i0 + 4 * ib, j = j0 + jj;
+        float z[4], sg = 0.f;
+        eps4(p.seed, p.offset, (unsigned)plane, (unsigned)(i >> 2), (unsigned)j, z);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sg = fmaf(gs[(4 * ib + k) * BT + jj], z[k], sg);   // gs is 0 outside the image
+        sred[l] = sg;
+    }
+    __syncthreads();
+    float* out = p.part + ((long long)plane * p.tiles + tile) * (VB_TAPS + 1);
+    if (tid < VB_TAPS) {
+        float a = red[tid];
+#pragma unroll
+        for (int k = 1; k < VB_S; ++k) a += red[k * VB_TAPS + tid];
+        out[tid] = a;
+    }
+    if (tid == 256) {
+        float a = 0.f;
+        if (p.want_sigma)
+            for (int k = 0; k < 64; ++k) a += sred[k];
+        out[VB_TAPS] = a;
+    }
+}
+
+// dk[plane][tap] = sum_tiles part[plane][tile][tap]; dsigma[plane] likewise.  Fixed summation order (8 interleaved
+// running sums per output, combined pairwise) so results are bit-reproducible; the 8 loads of a round are independent,
+// which keeps the tile loop from serialising on memory latency.
 __global__ void degrade_bwd_reduce_kernel(const float* __restrict__ part, int tiles, int ntaps, float* __restrict__ dk,
                                           float* __restrict__ dsigma) {
     const int plane = blockIdx.x;
-    const float* pp = part + (long long)plane * tiles * (ntaps + 1);
+    const long long pitch = ntaps + 1;
+    const float* pp = part + (long long)plane * tiles * pitch;
     for (int t = threadIdx.x; t <= ntaps; t += blockDim.x) {
-        float a = 0.f;
-        for (int k = 0; k < tiles; ++k) a += pp[(long long)k * (ntaps + 1) + t];
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= tiles; k += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] += pp[(k + q) * pitch + t];
+        }
+        for (int q = 0; k < tiles; ++k, ++q) a[q] += pp[k * pitch + t];
+        const float r = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         if (t < ntaps) {
-            if (dk) dk[(long long)plane * ntaps + t] = a;
+            if (dk) dk[(long long)plane * ntaps + t] = r;
         } else if (dsigma) {
-            dsigma[plane] = a;
+            dsigma[plane] = r;
         }
     }
 }
@@ -195,10 +342,14 @@ extern "C" int kmsr_degrade_bwd_f32(const kmsr_degrade_desc* d, const float* hr,
     const long long nblocks = planes * p.tiles;
     if (nblocks > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "grid too large");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (lds > 64 * 1024)
-        KMSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(degrade_bwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    degrade_bwd_kernel<<<(int)nblocks, BTHREADS, lds, stream>>>(p);
+    if (p.F == VB_F && p.kh == VB_K && p.kw == VB_K) {
+        degrade_bwd_vb_kernel<<<(int)nblocks, BTHREADS, 0, stream>>>(p);
+    } else {
+        if (lds > 64 * 1024)
+            KMSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(degrade_bwd_kernel<0, 0>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        degrade_bwd_kernel<0, 0><<<(int)nblocks, BTHREADS, lds, stream>>>(p);
+    }
     KMSR_HIP_CHECK(hipGetLastError());
     degrade_bwd_reduce_kernel<<<(int)planes, 256, 0, stream>>>(p.part, p.tiles, ntaps, dkernels, dsigma);
     KMSR_HIP_CHECK(hipGetLastError());

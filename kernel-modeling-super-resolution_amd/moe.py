@@ -6,9 +6,9 @@ reference's `moe_model.pth` loads unchanged) and the same forward contract:
 
     out, weights, valid_kernels = model(x, temp=1.0, hard=False)       # train_gemini.py:88-140
 
-Runs on the GPU only.  eval() mode (or torch.no_grad()): inference -- BatchNorm uses the running statistics of the
-checkpoint, folded into the stride-2 convs (SURVEY 8a': the deployment mode).  train() mode with grad enabled: the
-differentiable path the reference's trainer runs (train_gemini.py:169-232 never calls .eval(), so BatchNorm uses batch
+Runs on the GPU only.  eval() mode: inference -- BatchNorm uses the running statistics of the checkpoint, folded
+into the stride-2 convs (SURVEY 8a': the deployment mode).  train() mode (the nn.Module default): the differentiable
+path the reference's trainer runs (train_gemini.py:169-232 never calls .eval(), so BatchNorm uses batch
 statistics there): selector convs through Conv3x3Function (HIP forward / dgrad / wgrad), degradation through
 DegradeFunction (HIP forward + kmsr_degrade_bwd_f32 for d/d kernel and d/d sigma); softmax / softplus / Gumbel /
 einsum over the tiny banks stay torch ops so autograd finishes the chain rule into kernel_bank, sigma_bank and the
@@ -56,7 +56,7 @@ class SelectorNet(nn.Module):
         L.require_gpu()
         if not x.is_cuda:
             raise L.KmsrError("SelectorNet.forward runs on the GPU only (no CPU fallback)")
-        if torch.is_grad_enabled() and self.training:
+        if self.training:          # batch-statistics BatchNorm also under no_grad (the trainer's D step, train_gemini.py:181-183)
             return self._forward_train(x)
         with torch.no_grad():
             return self._forward_infer(x)
@@ -112,7 +112,7 @@ class ContentAdaptiveDegradation(nn.Module):
     def forward(self, x, temp=1.0, hard=False, weights=None):
         """x [B,C,H,W] CUDA float32.  Returns (out [B,C,ceil(H/4),ceil(W/4)], weights [B,K], valid_kernels [K,C,k,k]).
         `weights` may be passed to bypass the Gumbel draw (tests / a uniformly random kernel per sample)."""
-        if torch.is_grad_enabled() and self.training:
+        if self.training:
             return self._forward_train(x, temp, hard, weights)
         with torch.no_grad():
             return self._forward_infer(x, temp, hard, weights)

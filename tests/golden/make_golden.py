@@ -361,6 +361,30 @@ def make_moe_backward_golden():
                                          sel.features[6].weight.grad.double().abs().sum().item()])
     out["sel_d_cls_w"] = sel.classifier.weight.grad.numpy()
     out["sel_running_mean1"] = sel.features[1].running_mean.numpy()
+    # losses (muti_kernel/loss.py:6-41) and the critic (muti_kernel/networks.py:250-268) the same trainer uses
+    L = m["mloss"]
+    ks = np.load(f"{REF}/moe_kernels/kernel_0.npy")
+    kneg = ks[0] - 0.004
+    out["kreg_kernel0"] = np.array([L.kernel_regularization(torch.from_numpy(ks[c]), alpha=0.5).item() for c in range(5)])
+    out["kreg_neg"] = np.array([L.kernel_regularization(torch.from_numpy(kneg)).item()])
+    pr = torch.randn(2, 1, 8, 8, generator=torch.Generator().manual_seed(34))
+    pf = torch.randn(2, 1, 8, 8, generator=torch.Generator().manual_seed(35))
+    out["lsgan"] = np.array([L.lsgan_d_loss(pr, pf).item(), L.lsgan_g_loss(pf).item()])
+    nets = m["mnet"]
+    torch.manual_seed(0)
+    Dref = nets.PatchDiscriminator(in_ch=5)
+    for k_, v_ in Dref.state_dict().items():
+        out["D__" + k_] = v_.detach().clone().numpy()
+    xd = torch.randn(2, 5, 16, 16, generator=torch.Generator().manual_seed(36))
+    Dref.eval()
+    with torch.no_grad():
+        out["D_eval_out"] = Dref(xd).numpy()
+    Dref.train()
+    yd = Dref(xd)                      # one power iteration of every spectral norm + batch-statistics BatchNorm
+    yd.pow(2).mean().backward()
+    out["D_train_out"] = yd.detach().numpy()
+    out["D_train_u0"] = Dref.net[0].weight_u.detach().numpy()
+    out["D_train_d_w0"] = Dref.net[0].weight_orig.grad.numpy()
     out["meta"] = np.array([B, C, H, W, 31, 32, 33], np.int64)
     out["note"] = np.array("train_gemini.py:88-140,169-232; x=landsat_like((3,5,40,44),31), G=randn(seed 32) [3,5,10,11], "
                            "Gl=randn(seed 33) [3,10], moe_model.pth, train mode, temp=2.0")

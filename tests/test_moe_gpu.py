@@ -200,3 +200,34 @@ def test_degrade_backward_adjoint_identity_full_size(gpu_device):
     rhs = (dk.double() * K.double()).sum(dim=(2, 3))
     scale = (out.double().abs() * g.double().abs()).sum(dim=(2, 3))
     assert float(((lhs - rhs).abs() / scale).max()) < 1e-5
+
+
+def test_train_moe_runs_and_saves(gpu_device, tmp_path):
+    """train_gemini.py:145-254 end to end on the GPU: a few D/G iterations move the banks and the selector, losses stay
+    finite, the log line and the saved artefacts have the reference's format (kernel_<i>.npy / sigma_<i>.npy / moe_model.pth)."""
+    torch.manual_seed(0)
+    model = kmsr_amd.ContentAdaptiveDegradation(10, 5, 13).cuda()
+    D = kmsr_amd.PatchDiscriminator(5).cuda()
+    patches = torch.from_numpy(landsat_like((4, 5, 64, 64), 50)).cuda()
+    real = torch.randn(4, 5, 16, 16, device=gpu_device) * 5 + 60
+    k0, s0 = model.kernel_bank.detach().clone(), model.sigma_bank.detach().clone()
+    c0 = model.selector.features[0].weight.detach().clone()
+    lines = []
+    hist = kmsr_amd.train_moe(model, D, patches, real, total_iters=6, log_every=3, log=lines.append)
+    assert hist.shape == (6, 3) and np.isfinite(hist).all()
+    assert not torch.equal(k0, model.kernel_bank) and not torch.equal(s0, model.sigma_bank)
+    assert not torch.equal(c0, model.selector.features[0].weight)
+    assert len(lines) == 2 and lines[0].startswith("Iter 0 | Temp: 5.00 | D: ") and "Selection Dist: [" in lines[0]
+    assert model.noise_offset == 12                      # two forwards per iteration, each on a fresh noise offset
+    kmsr_amd.save_moe(model, str(tmp_path))
+    for i in range(10):
+        k = np.load(tmp_path / f"kernel_{i}.npy")
+        s = np.load(tmp_path / f"sigma_{i}.npy")
+        assert k.shape == (5, 13, 13) and k.dtype == np.float32 and np.allclose(k.sum(axis=(1, 2)), 1.0, atol=1e-5)
+        assert s.shape == (5,) and (s > 0).all()
+    sd = torch.load(tmp_path / "moe_model.pth", weights_only=True, map_location="cpu")
+    kmsr_amd.ContentAdaptiveDegradation(10, 5, 13).load_state_dict(sd)
+    # the trained model serves the deployment path: eval() forward with hard selection
+    model.eval()
+    out, w, _ = model(patches, hard=True)
+    assert out.shape == (4, 5, 16, 16) and bool(torch.isfinite(out).all()) and bool((w.sum(1) == 1).all())

@@ -218,3 +218,42 @@ def test_vb_backward_matches_reference_autograd():
     assert_close(bank.grad.numpy(), MB["d_kernel_bank"], rtol=2e-4, atol=1e-6 * np.abs(MB["d_kernel_bank"]).max(),
                  what="d kernel_bank")
 
+
+
+def test_moe_trainer_losses_match_reference():
+    """kmsr_amd.train_moe losses == muti_kernel/loss.py:6-41 on the shipped kernel_0 and on seeded tensors."""
+    import torch
+    import kmsr_amd
+    MB = golden("moe_backward.npz")
+    ks = np.asarray(golden("kernels.npz")["moe_kernels"])[0]
+    got = [float(kmsr_amd.kernel_regularization(torch.from_numpy(ks[c]), alpha=0.5)) for c in range(5)]
+    assert_close(np.array(got), MB["kreg_kernel0"], rtol=1e-5, atol=1e-6, what="kernel_regularization")
+    assert_close(np.array([float(kmsr_amd.kernel_regularization(torch.from_numpy(ks[0] - 0.004)))]), MB["kreg_neg"],
+                 rtol=1e-5, atol=1e-6, what="kernel_regularization with negative taps")
+    pr = torch.randn(2, 1, 8, 8, generator=torch.Generator().manual_seed(34))
+    pf = torch.randn(2, 1, 8, 8, generator=torch.Generator().manual_seed(35))
+    got = np.array([float(kmsr_amd.lsgan_d_loss(pr, pf)), float(kmsr_amd.lsgan_g_loss(pf))])
+    assert_close(got, MB["lsgan"], rtol=1e-6, atol=1e-7, what="lsgan losses")
+
+
+def test_patch_discriminator_matches_reference():
+    """PatchDiscriminator (muti_kernel/networks.py:250-268): the reference's state_dict loads key for key; eval and
+    train-mode (spectral-norm power iteration + batch-statistics BN) outputs and a weight gradient match."""
+    import torch
+    import kmsr_amd
+    MB = golden("moe_backward.npz")
+    sd = {k[3:]: torch.from_numpy(np.asarray(MB[k])) for k in MB.files if k.startswith("D__")}
+    D = kmsr_amd.PatchDiscriminator(in_ch=5)
+    assert set(D.state_dict().keys()) == set(sd.keys())
+    D.load_state_dict(sd)
+    xd = torch.randn(2, 5, 16, 16, generator=torch.Generator().manual_seed(36))
+    D.eval()
+    with torch.no_grad():
+        assert_close(D(xd).numpy(), MB["D_eval_out"], rtol=1e-4, atol=1e-5, what="D eval output")
+    D.train()
+    yd = D(xd)
+    yd.pow(2).mean().backward()
+    assert_close(yd.detach().numpy(), MB["D_train_out"], rtol=1e-4, atol=1e-5, what="D train output")
+    assert_close(D.net[0].weight_u.numpy(), MB["D_train_u0"], rtol=1e-5, atol=1e-6, what="spectral-norm u after one step")
+    assert_close(D.net[0].weight_orig.grad.numpy(), MB["D_train_d_w0"], rtol=1e-3,
+                 atol=1e-4 * np.abs(MB["D_train_d_w0"]).max(), what="d weight_orig")
