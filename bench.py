@@ -175,10 +175,19 @@ class DegradeSRWorkload:
         ms = [a.elapsed_time(b) for a, b in self._events]
         kernel_ms = sum(ms) / max(len(ms), 1)
         achieved = self.body_flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        # HBM bytes per launch of this kernel cannot be counted inside this process: they come from the committed PMC passes
+        # of this same command (tools/pmc_traffic.sh -> profiles/r01_bench_pmc_traffic.json), null if that file is absent
+        traffic, src = None, None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_pmc_traffic.json")) as f:
+                pm = json.load(f)
+            traffic, src = pm["traffic_bytes_per_launch"], "profiles/r01_bench_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+        except (OSError, KeyError, ValueError):
+            pass
         return {"bound": "mfma", "kernel": "conv3x3_wino_kernel<false> (3x3 conv 64->64 @256x256, batch 16; Winograd F(2x2,3x3) on fp32 MFMA; "
                                            "33 launches/step; achieved = direct-conv algorithmic FLOPs / time)",
                 "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
                 "algorithmic_flops_per_launch": self.body_flops_per_launch, "kernel_ms": round(kernel_ms, 4),
                 "launches_timed": len(ms),
                 "step_tflops": None}
