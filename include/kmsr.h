@@ -219,6 +219,15 @@ int kmsr_conv3x3_wino_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int3
 int kmsr_conv3x3_wino_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
                               const float* residual, float* out, void* stream);
 
+/* LDS-DMA variant of the Winograd kernel: same math, epilogues and tolerances; input rows and transformed weights go
+ * global -> LDS directly (no register staging), 8-channel chunks (packed layout [ceil(Cout/64)][ceil(Cin/8)][16][8][64]).
+ * Needs W % 4 == 0 and 16-byte aligned x / packed_w; everything else is served by kmsr_conv3x3_wino_fwd_f32. */
+size_t kmsr_conv3x3_winod_packed_weight_floats(int32_t Cin, int32_t Cout);
+int kmsr_conv3x3_winod_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int32_t Cin, int32_t Cout, float* packed,
+                                        void* stream);
+int kmsr_conv3x3_winod_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
+                               const float* residual, float* out, void* stream);
+
 /* ============================================================================================
  * 5x5 convolution (zero padding 2) with PixelShuffle(4) fused into the store -- the COLLAPSED SR upsampler.
  * up1 (3x3 F->4F) -> PixelShuffle(2) -> up2 (3x3 F->4F) -> PixelShuffle(2) -> tail (3x3 F->bands) contains no

@@ -45,6 +45,18 @@ def pack_conv3x3_weight_wino(weight):
     return packed
 
 
+def pack_conv3x3_weight_wino_dma(weight):
+    """[Cout,Cin,3,3] -> G g G^T packed in 8-channel chunks for conv3x3(..., algo="winograd_dma")."""
+    lib = L.load()
+    assert weight.is_cuda and weight.dtype == torch.float32 and weight.ndim == 4 and weight.shape[2:] == (3, 3)
+    w = weight.detach().contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    packed = torch.empty(lib.kmsr_conv3x3_winod_packed_weight_floats(Cin, Cout), device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        L.check(lib.kmsr_conv3x3_winod_pack_weights_f32(L.ptr(w), Cin, Cout, L.ptr(packed), L.current_stream()))
+    return packed
+
+
 def winograd_eligible(cin, cout, stride=1, width=2):
     """Where the Winograd kernel applies/pays: stride 1, even width (patch rows are fetched as aligned float2) and
     enough channels that the 64x16 chunk tiles are not mostly padding."""
@@ -64,10 +76,11 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     d = L.Conv3x3Desc()
     d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, Cin, H, W, int(cout), int(stride)
     d.relu, d.pixel_shuffle = int(bool(relu)), int(bool(pixel_shuffle))
-    wino = algo == "winograd"
+    wino = algo in ("winograd", "winograd_dma")
     if wino and stride != 1:
         raise NotImplementedError("winograd conv needs stride 1")
-    need = (lib.kmsr_conv3x3_wino_packed_weight_floats if wino else lib.kmsr_conv3x3_packed_weight_floats)(Cin, int(cout))
+    need = {"direct": lib.kmsr_conv3x3_packed_weight_floats, "winograd": lib.kmsr_conv3x3_wino_packed_weight_floats,
+            "winograd_dma": lib.kmsr_conv3x3_winod_packed_weight_floats}[algo](Cin, int(cout))
     assert packed_w.is_cuda and packed_w.dtype == torch.float32 and packed_w.numel() == need, \
         f"packed weight has {packed_w.numel()} floats, conv {Cin}->{cout} needs {need}"
     oshape = (N, cout // 4, 2 * Ho, 2 * Wo) if pixel_shuffle else (N, cout, Ho, Wo)
@@ -82,7 +95,8 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
         residual = residual.contiguous()
         assert tuple(residual.shape) == oshape and residual.is_cuda
     with torch.cuda.device(x.device):
-        fwd = lib.kmsr_conv3x3_wino_fwd_f32 if wino else lib.kmsr_conv3x3_fwd_f32
+        fwd = {"direct": lib.kmsr_conv3x3_fwd_f32, "winograd": lib.kmsr_conv3x3_wino_fwd_f32,
+               "winograd_dma": lib.kmsr_conv3x3_winod_fwd_f32}[algo]
         L.check(fwd(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out), L.current_stream()))
     return out
 

@@ -97,6 +97,35 @@ def test_conv3x3_winograd_vs_torch(N, Cin, H, W, Cout, bias, relu, res, ps, gpu_
     _check(out, direct.double(), tol=2e-5, what="winograd vs direct")
 
 
+WINOD_CASES = [
+    (2, 64, 40, 72, 64, True, True, False, False),      # ragged tiles (H % 4 != 0, W % 64 != 0)
+    (1, 64, 4, 64, 64, True, False, True, False),       # exactly one workgroup tile, residual
+    (1, 64, 24, 40, 256, True, False, False, True),     # upsampler: 4 cout groups + fused PixelShuffle
+    (2, 16, 33, 48, 32, False, True, True, False),      # two 8-channel chunks, odd height, relu + residual
+    (1, 100, 9, 132, 70, True, False, False, False),    # Cin / Cout not multiples of 8 / 64, 3 column tiles
+    (1, 20, 3, 4, 32, True, True, False, True),         # 3x4 image: most lanes outside the image, + PixelShuffle
+    (1, 8, 70, 128, 64, True, False, True, False),      # a single chunk (no prefetch), many row tiles
+]
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,bias,relu,res,ps", WINOD_CASES)
+def test_conv3x3_winograd_dma_vs_torch(N, Cin, H, W, Cout, bias, relu, res, ps, gpu_device):
+    """LDS-DMA Winograd variant: same semantics and tolerance as the register-staged Winograd kernel."""
+    from kmsr_amd.sr import pack_conv3x3_weight_wino_dma
+    g = torch.Generator().manual_seed(11 * N + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g) if bias else None
+    oshape = (N, Cout // 4, 2 * H, 2 * W) if ps else (N, Cout, H, W)
+    r = torch.randn(*oshape, generator=g) if res else None
+    out = conv3x3(x.cuda(), pack_conv3x3_weight_wino_dma(w.cuda()), Cout, bias=None if b is None else b.cuda(), relu=relu,
+                  residual=None if r is None else r.cuda(), pixel_shuffle=ps, algo="winograd_dma")
+    assert tuple(out.shape) == oshape
+    _check(out, _ref_conv(x, w, b, relu, r, ps), tol=2e-5, what=f"winograd_dma {Cin}->{Cout} {H}x{W}")
+    with pytest.raises(NotImplementedError):            # W % 4 != 0 is served by the register-staged kernel
+        conv3x3(torch.zeros(1, Cin, 4, 6, device=gpu_device), pack_conv3x3_weight_wino_dma(w.cuda()), Cout, algo="winograd_dma")
+
+
 def test_conv3x3_tap_orientation_and_channel_map(gpu_device):
     """A = permutation check with asymmetric data: w[co,ci,u,v] = 1 iff ci == perm[co] and (u,v) == shift[co].
     Every output channel must equal ONE input channel shifted by one specific tap -- catches transposed taps

@@ -6,8 +6,9 @@ torch.cuda.set_device(0)
 N, Cin, H, W, Cout = 16, 64, 256, 256, 64
 x = torch.randn(N, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05; b = torch.randn(Cout, device="cuda")
 algo = os.environ.get("ALGO", "direct")
+from kmsr_amd.sr import pack_conv3x3_weight_wino_dma
 from kmsr_amd.sr import pack_conv3x3_weight_wino
-pw = pack_conv3x3_weight_wino(w) if algo == "winograd" else pack_conv3x3_weight(w); out = conv3x3(x, pw, Cout, bias=b, algo=algo); torch.cuda.synchronize()
+pw = {"winograd": pack_conv3x3_weight_wino, "winograd_dma": pack_conv3x3_weight_wino_dma, "direct": pack_conv3x3_weight}[algo](w); out = conv3x3(x, pw, Cout, bias=b, algo=algo); torch.cuda.synchronize()
 ts = []
 for _ in range(7):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
