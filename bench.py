@@ -184,7 +184,7 @@ class DegradeSRWorkload:
             traffic, src = pm["traffic_bytes_per_launch"], "profiles/r01_bench_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         except (OSError, KeyError, ValueError):
             pass
-        return {"bound": "mfma", "kernel": "conv3x3_wino_kernel<false> (3x3 conv 64->64 @256x256, batch 16; Winograd F(2x2,3x3) on fp32 MFMA; "
+        return {"bound": "mfma", "kernel": "conv3x3_winod_kernel<false> (3x3 conv 64->64 @256x256, batch 16; Winograd F(2x2,3x3) on fp32 MFMA, LDS-DMA staged; "
                                            "33 launches/step; achieved = direct-conv algorithmic FLOPs / time)",
                 "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,

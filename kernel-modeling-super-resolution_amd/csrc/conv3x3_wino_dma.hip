@@ -198,8 +198,30 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winod_kernel(const float*
     if (nch > 1) issue_dma(1, 1);
     transform(0, 0);
     sync_lds();
+    // residual (skip) values of the outputs this wave finalises, [4g + r] <-> channel co0(g) + r, pixel pair (ry, rx0..rx0+1):
+    // fetched at the start of the LAST chunk's MFMA phase (no staging registers compete for the space in this kernel)
+    f32x2 rres[16];
+    const int ry = ty0 + 2 * tb + ih, rx0 = tx0 + 2 * l32;
+    auto prefetch_residual = [&]() {
+        if constexpr (!PS) {
+            if (res) {                                       // block-uniform
+                const long long plane = (long long)H * W;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co0 = cg * DCO + cbk * 32 + 8 * g + 4 * half;
+                    const long long base = ((long long)n * p.Cout + co0) * plane + (long long)ry * W + rx0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = ry < H && rx0 < W && co0 + r < p.Cout;
+                        rres[4 * g + r] = *reinterpret_cast<const f32x2*>(res + (ok ? base + r * plane : 0));   // masked at use
+                    }
+                }
+            }
+        }
+    };
     for (int chunk = 0; chunk < nch; ++chunk) {
         const float* ub = lds + OFF_U + (chunk & 1) * DUF;
+        if (chunk + 1 == nch) prefetch_residual();
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
 #pragma unroll
@@ -278,12 +300,11 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winod_kernel(const float*
             f32x2 rr[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) rr[r] = f32x2{0.f, 0.f};
-            if (res) {   // block-uniform; loads issued together from clamped-safe addresses
+            if (res) {   // block-uniform; fetched during the last chunk's MFMA phase (prefetch_residual)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool ok = pok2 && co0 + r < p.Cout;
-                    const f32x2 v = *reinterpret_cast<const f32x2*>(res + (ok ? base + r * plane : 0));
-                    rr[r] = ok ? v : f32x2{0.f, 0.f};
+                    rr[r] = ok ? rres[4 * g + r] : f32x2{0.f, 0.f};
                 }
             }
 #pragma unroll

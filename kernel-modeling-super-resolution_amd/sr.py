@@ -63,10 +63,24 @@ def winograd_eligible(cin, cout, stride=1, width=2):
     return stride == 1 and width % 2 == 0 and cin >= 16 and cout >= 32
 
 
+def pick_algo(cin, cout, stride, width, use_winograd=True):
+    """Kernel for a stride-1 3x3 conv of this shape: the LDS-DMA Winograd variant when rows are 16-byte aligned
+    (W % 4 == 0), the register-staged Winograd kernel for other even widths, the direct MFMA / VALU kernels otherwise."""
+    if not (use_winograd and winograd_eligible(cin, cout, stride, width)):
+        return "direct"
+    return "winograd_dma" if width % 4 == 0 else "winograd"
+
+
+def pack_for(algo, weight):
+    return {"direct": pack_conv3x3_weight, "winograd": pack_conv3x3_weight_wino,
+            "winograd_dma": pack_conv3x3_weight_wino_dma}[algo](weight)
+
+
 def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuffle=False, stride=1, out=None,
             algo="direct"):
     """out = epilogue(conv3x3(x, w)) with zero padding 1 (semantics: include/kmsr.h).  x [N,Cin,H,W] float32 CUDA.
-    algo="direct": packed_w from pack_conv3x3_weight; algo="winograd": packed_w from pack_conv3x3_weight_wino."""
+    algo="direct": packed_w from pack_conv3x3_weight; "winograd" / "winograd_dma": from pack_conv3x3_weight_wino[_dma]
+    (pick_algo / pack_for choose and pack for a shape)."""
     lib = L.load()
     if not (x.is_cuda and x.dtype == torch.float32 and x.ndim == 4):
         raise ValueError("x must be a 4-D float32 CUDA tensor")
@@ -130,9 +144,8 @@ class Conv3x3Function(torch.autograd.Function):
     @staticmethod
     def _run(x, w, bias, relu):
         cout, cin = w.shape[0], w.shape[1]
-        if Conv3x3Function.use_winograd and winograd_eligible(cin, cout, 1, x.shape[-1]):
-            return conv3x3(x, pack_conv3x3_weight_wino(w), cout, bias=bias, relu=relu, algo="winograd")
-        return conv3x3(x, pack_conv3x3_weight(w), cout, bias=bias, relu=relu)
+        algo = pick_algo(cin, cout, 1, x.shape[-1], Conv3x3Function.use_winograd)
+        return conv3x3(x, pack_for(algo, w), cout, bias=bias, relu=relu, algo=algo)
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
@@ -167,11 +180,11 @@ class _PackCache:
         self.key = None
         self.packed = None
 
-    def get(self, conv, wino=False):
+    def get(self, conv, algo="direct"):
         w = conv.weight
-        key = (w.data_ptr(), w._version, w.device, wino)
+        key = (w.data_ptr(), w._version, w.device, algo)
         if key != self.key:
-            self.packed = pack_conv3x3_weight_wino(w) if wino else pack_conv3x3_weight(w)
+            self.packed = pack_for(algo, w)
             self.key = key
         return self.packed
 
@@ -276,15 +289,17 @@ class _FusedUpsampler:
                     w, b = cv.weight.detach().transpose(2, 3).contiguous(), (cv.bias.detach().contiguous() if cv.bias is not None else None)
                 else:
                     w, b = self._swap_subpixels(cv)
-                ls.append((w, b, pack_conv3x3_weight(w), pack_conv3x3_weight_wino(w) if winograd_eligible(w.shape[1], w.shape[0]) else None))
+                ls.append((w, b, {}))           # packed weights per algorithm, filled on first use
             self.layers[tag] = ls
         self.key = key
 
     def _chain(self, tag, s, use_wino):
         """up1 -> PS -> up2 -> PS -> tail on a strip batch [M,F,R,L] with the HIP 3x3 kernels."""
-        for i, (w, b, pk, pkw) in enumerate(self.layers[tag]):
-            wino = use_wino and pkw is not None and winograd_eligible(w.shape[1], w.shape[0], 1, s.shape[-1])
-            s = conv3x3(s, pkw if wino else pk, w.shape[0], bias=b, pixel_shuffle=i < 2, algo="winograd" if wino else "direct")
+        for i, (w, b, packs) in enumerate(self.layers[tag]):
+            algo = pick_algo(w.shape[1], w.shape[0], 1, s.shape[-1], use_wino)
+            if algo not in packs:
+                packs[algo] = pack_for(algo, w)
+            s = conv3x3(s, packs[algo], w.shape[0], bias=b, pixel_shuffle=i < 2, algo=algo)
         return s
 
     def __call__(self, net, h):
@@ -326,16 +341,15 @@ class SRNet(nn.Module):
         self.fuse_upsampler = False  # inference path, x4 only: collapse up1/PS/up2/PS/tail into one 5x5 conv + PS4 (opt-in)
         self._fused_up = _FusedUpsampler()
 
-    def _packed(self, name, conv, wino=False):
+    def _packed(self, name, conv, algo="direct"):
         c = self._caches.get(name)
         if c is None:
             c = self._caches[name] = _PackCache()
-        return c.get(conv, wino)
+        return c.get(conv, algo)
 
     def _conv(self, name, conv, x, **kw):
-        wino = self.use_winograd and winograd_eligible(conv.in_channels, conv.out_channels, 1, x.shape[-1])
-        return conv3x3(x, self._packed(name, conv, wino), conv.out_channels, bias=conv.bias,
-                       algo="winograd" if wino else "direct", **kw)
+        algo = pick_algo(conv.in_channels, conv.out_channels, 1, x.shape[-1], self.use_winograd)
+        return conv3x3(x, self._packed(name, conv, algo), conv.out_channels, bias=conv.bias, algo=algo, **kw)
 
     def forward(self, x):
         """eval() mode or torch.no_grad(): the fused inference path.  train() mode with grad enabled (or an input that
