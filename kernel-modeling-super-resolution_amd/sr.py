@@ -85,6 +85,8 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     if not (x.is_cuda and x.dtype == torch.float32 and x.ndim == 4):
         raise ValueError("x must be a 4-D float32 CUDA tensor")
     x = x.contiguous()
+    if algo == "winograd_dma" and x.data_ptr() % 16:
+        x = x.clone()                    # a view at an odd storage offset: the LDS-DMA kernel fetches 16-byte pieces
     N, Cin, H, W = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     d = L.Conv3x3Desc()
