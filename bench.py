@@ -343,9 +343,16 @@ def main():
     args = ap.parse_args()
 
     from kmsr_amd import dist as kd
-    rank, world, local = kd.init_from_env(backend="nccl")      # "nccl" is RCCL on ROCm; no group for a single process
-    torch.cuda.set_device(local if world > 1 else 0)
-    device = torch.device("cuda", local if world > 1 else 0)
+    # "nccl" is RCCL on ROCm; no group for a single process.  Rehearsal on a one-GPU box (several ranks sharing card 0,
+    # which RCCL refuses): KMSR_BENCH_BACKEND=gloo KMSR_BENCH_DEVICE=0 -- exercises the rank / barrier / MAX logic only.
+    backend = os.environ.get("KMSR_BENCH_BACKEND", "nccl")
+    forced = os.environ.get("KMSR_BENCH_DEVICE")
+    if forced is not None:
+        os.environ["LOCAL_RANK_ORIG"] = os.environ.get("LOCAL_RANK", "0")
+    rank, world, local = kd.init_from_env(backend=backend)
+    dev_index = int(forced) if forced is not None else (local if world > 1 else 0)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     L.require_gpu()
 
     wl = {"degrade_sr": DegradeSRWorkload, "degrade": DegradeWorkload, "train": TrainWorkload, "sr_bf16": SRBf16Workload}[args.workload](device, rank)
