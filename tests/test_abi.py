@@ -153,3 +153,16 @@ def test_compose_upsampler_is_the_interior_operator():
     f = F.pixel_shuffle(F.conv2d(h, w5.double(), b5.double(), padding=2), 4)
     d = (r - f).abs()
     assert float(d[:, :, 3:-3, 3:-3].max()) < 1e-6 and float(d.max()) > 1e-3   # the frame is where they differ
+
+
+def test_pick_algo_dispatch():
+    """Host-side kernel choice for a stride-1 3x3 conv (kmsr_amd/sr.py: pick_algo)."""
+    from kmsr_amd.sr import pick_algo
+    assert pick_algo(64, 64, 1, 256) == "winograd_dma"          # rows 16-byte aligned -> LDS-DMA staged Winograd
+    assert pick_algo(64, 256, 1, 512) == "winograd_dma"
+    assert pick_algo(64, 64, 1, 70) == "winograd"               # even width only -> register-staged Winograd
+    assert pick_algo(64, 64, 1, 71) == "direct"                 # odd width
+    assert pick_algo(3, 64, 1, 256) == "direct"                 # head: too few input channels
+    assert pick_algo(64, 3, 1, 1024) == "direct"                # tail: small-Cout VALU kernel
+    assert pick_algo(64, 64, 2, 256) == "direct"                # stride 2 (selector)
+    assert pick_algo(64, 64, 1, 256, use_winograd=False) == "direct"
