@@ -63,7 +63,7 @@ __global__ void bf16_pack_kernel(const float* __restrict__ w, int Cin, int Cout,
     }
 }
 
-template <bool PS>
+template <bool PS, int KS>          // KS = padded Cin / 16
 __global__ void __launch_bounds__(256, 1) conv3x3_bf16_kernel(const unsigned short* __restrict__ xg,
                                                               const unsigned short* __restrict__ wpk,
                                                               const float* __restrict__ bias,
@@ -134,19 +134,29 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_kernel(const unsigned sho
                 for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
         const unsigned short* ap = wl + l32 * CP + 8 * half;                          // + (tap*64 + 32*mt)*CP + 16*ks
         const unsigned short* bp = il + ((2 * wv) * BIW + l32) * CP + 8 * half;       // + ((nt+dy)*BIW + dx)*CP + 16*ks
+        // 9 x KS operand groups (A: 2 x 16 B of weights, B: 2 x 16 B of pixels, 4 MFMAs each).  One wave per SIMD: nothing
+        // else covers an LDS round trip, so group g+1 is requested before group g is multiplied; the asm pins keep the
+        // compiler from sinking the reads next to their MFMAs (it otherwise emits read,read,read,read,wait,4 x mfma).
+        constexpr int NG = 9 * KS;
+        auto fetch_group = [&](int g, bf16x8& a0, bf16x8& a1, bf16x8& b0, bf16x8& b1) {
+            const int tap = g / KS, ks = g % KS, dy = tap / 3, dx = tap % 3;
+            a0 = *reinterpret_cast<const bf16x8*>(ap + (tap * BCO) * CP + 16 * ks);
+            a1 = *reinterpret_cast<const bf16x8*>(ap + (tap * BCO + 32) * CP + 16 * ks);
+            b0 = *reinterpret_cast<const bf16x8*>(bp + (dy * BIW + dx) * CP + 16 * ks);
+            b1 = *reinterpret_cast<const bf16x8*>(bp + ((1 + dy) * BIW + dx) * CP + 16 * ks);
+        };
+        bf16x8 ca0, ca1, cb0, cb1;
+        fetch_group(0, ca0, ca1, cb0, cb1);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
-            for (int ks = 0; ks < Cin / 16; ++ks) {
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap + (tap * BCO) * CP + 16 * ks);
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + (tap * BCO + 32) * CP + 16 * ks);
-                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bp + (dy * BIW + dx) * CP + 16 * ks);
-                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(bp + ((1 + dy) * BIW + dx) * CP + 16 * ks);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-            }
+        for (int g = 0; g < NG; ++g) {
+            bf16x8 na0 = ca0, na1 = ca1, nb0 = cb0, nb1 = cb1;
+            if (g + 1 < NG) fetch_group(g + 1, na0, na1, nb0, nb1);
+            asm volatile("" : "+v"(ca0), "+v"(ca1), "+v"(cb0), "+v"(cb1));
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca0, cb0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca0, cb1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca1, cb0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca1, cb1, acc[1][1], 0, 0, 0);
+            ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;
         }
         __syncthreads();                                     // all waves are done reading the input tile -> reuse it for staging
 
@@ -287,15 +297,23 @@ extern "C" int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x, 
     const auto* ws = static_cast<const unsigned short*>(packed_w);
     const auto* rs = static_cast<const unsigned short*>(residual);
     auto* os = static_cast<unsigned short*>(out);
-    if (d->pixel_shuffle) {
-        KMSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        conv3x3_bf16_kernel<true><<<grid, 256, shmem, stream>>>(xs, ws, bias, rs, os, p);
-    } else {
-        KMSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        conv3x3_bf16_kernel<false><<<grid, 256, shmem, stream>>>(xs, ws, bias, rs, os, p);
+    auto launch = [&](auto kern) -> int {
+        KMSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        kern<<<grid, 256, shmem, stream>>>(xs, ws, bias, rs, os, p);
+        return KMSR_OK;
+    };
+    int rc = KMSR_OK;
+    const int ks = d->Cin / 16;
+#define KMSR_BF16_LAUNCH(PS_)                                                                       \
+    switch (ks) {                                                                                   \
+        case 1: rc = launch(conv3x3_bf16_kernel<PS_, 1>); break;                                    \
+        case 2: rc = launch(conv3x3_bf16_kernel<PS_, 2>); break;                                    \
+        case 3: rc = launch(conv3x3_bf16_kernel<PS_, 3>); break;                                    \
+        default: rc = launch(conv3x3_bf16_kernel<PS_, 4>); break;                                   \
     }
+    if (d->pixel_shuffle) { KMSR_BF16_LAUNCH(true) } else { KMSR_BF16_LAUNCH(false) }
+#undef KMSR_BF16_LAUNCH
+    if (rc != KMSR_OK) return rc;
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
 }
