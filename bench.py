@@ -189,6 +189,9 @@ class DegradeSRWorkload:
                 "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
                 "algorithmic_flops_per_launch": self.body_flops_per_launch, "kernel_ms": round(kernel_ms, 4),
+                # the Winograd kernel ISSUES 2.25x fewer MFMA flops than the algorithmic (direct-conv) count, which is why
+                # `frac` can exceed 1; the matrix pipe's own utilisation is reported beside it
+                "mfma_issued_tflops": round(achieved / 2.25, 2), "mfma_pipe_frac": round(achieved / 2.25 / F32_MFMA_PEAK_TFLOPS, 4),
                 "launches_timed": len(ms),
                 "step_tflops": None}
 
