@@ -144,16 +144,21 @@ class Conv3x3Function(torch.autograd.Function):
     use_winograd = True
 
     @staticmethod
-    def _run(x, w, bias, relu):
+    def _run(x, w, bias, relu, residual=None, pixel_shuffle=False):
         cout, cin = w.shape[0], w.shape[1]
         algo = pick_algo(cin, cout, 1, x.shape[-1], Conv3x3Function.use_winograd)
-        return conv3x3(x, pack_for(algo, w), cout, bias=bias, relu=relu, algo=algo)
+        return conv3x3(x, pack_for(algo, w), cout, bias=bias, relu=relu, residual=residual, pixel_shuffle=pixel_shuffle,
+                       algo=algo)
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
+    def forward(ctx, x, weight, bias, relu, residual=None, pixel_shuffle=False):
+        """residual (same shape as the conv output) is added and PixelShuffle(2) applied in the kernel's epilogue, so the
+        training graph has no separate add / permutation passes in the forward direction."""
         x = x.contiguous()
-        y = Conv3x3Function._run(x, weight.detach(), bias, relu)
+        y = Conv3x3Function._run(x, weight.detach(), bias, relu, residual, pixel_shuffle)
         ctx.relu = relu
+        ctx.pixel_shuffle = pixel_shuffle
+        ctx.has_residual = residual is not None
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.has_bias = bias is not None
         return y
@@ -161,10 +166,12 @@ class Conv3x3Function(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
+        if ctx.pixel_shuffle:
+            g = torch.nn.functional.pixel_unshuffle(g, 2)     # gradient in the conv-output layout
         g = g.contiguous()
         if ctx.relu:
             g = g * (y > 0)
-        dx = dw = db = None
+        dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             # data gradient = the same convolution with w'[ci,co,u,v] = w[co,ci,2-u,2-v]
             dx = Conv3x3Function._run(g, weight.detach().flip(2, 3).transpose(0, 1).contiguous(), None, False)
@@ -172,7 +179,9 @@ class Conv3x3Function(torch.autograd.Function):
             dw = conv3x3_wgrad(x, g)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = g.sum(dim=(0, 2, 3))
-        return dx, dw, db, None
+        if ctx.has_residual and ctx.needs_input_grad[4]:
+            dres = g                                          # y = conv(x) + residual
+        return dx, dw, db, None, dres, None
 
 
 class _PackCache:
@@ -365,16 +374,16 @@ class SRNet(nn.Module):
             return self._forward_infer(x)
 
     def _forward_train(self, x):
-        """Same network with autograd: every conv is Conv3x3Function (HIP forward, dgrad and wgrad); residual adds and
-        PixelShuffle are plain torch ops here (memory-bound permutations / adds, differentiable for free)."""
-        cv = lambda conv, t, relu=False: Conv3x3Function.apply(t, conv.weight, conv.bias, relu)
+        """Same network with autograd: every conv is Conv3x3Function (HIP forward, dgrad and wgrad) with the residual adds
+        and PixelShuffle fused into the forward kernels' epilogues; only the backward of PixelShuffle is a torch permutation."""
+        cv = lambda conv, t, relu=False, residual=None, ps=False: Conv3x3Function.apply(t, conv.weight, conv.bias, relu, residual, ps)
         f = cv(self.head, x)
         h = f
         for blk in self.body:
-            h = h + cv(blk.conv2, cv(blk.conv1, h, True))
-        h = cv(self.body_tail, h) + f
+            h = cv(blk.conv2, cv(blk.conv1, h, True), residual=h)
+        h = cv(self.body_tail, h, residual=f)
         for up in self.up:
-            h = torch.nn.functional.pixel_shuffle(cv(up, h), 2)
+            h = cv(up, h, ps=True)
         return cv(self.tail, h)
 
     def _forward_infer(self, x):
