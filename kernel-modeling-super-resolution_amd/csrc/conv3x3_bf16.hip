@@ -70,14 +70,14 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_kernel(const unsigned sho
                                                               const unsigned short* __restrict__ res,
                                                               unsigned short* __restrict__ out, Bf16Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    const int Cin = p.Cin, CP = Cin + PADE;                  // LDS pitch of one pixel / one weight row (elements)
+    constexpr int Cin = 16 * KS, CP = Cin + PADE;            // compile-time: LDS pitch of one pixel / one weight row (elements)
     unsigned short* wl = smem;                               // [9][64][CP]
     unsigned short* il = smem + 9 * BCO * CP;                // [10][34][CP]   (reused as the output staging tile)
     float* sbias = reinterpret_cast<float*>(il + tile_region_elems(Cin));   // [64]
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.H, W = p.W;
-    const int kvec = Cin / 8;                                // 16-byte vectors per pixel / weight row
+    constexpr int kvec = Cin / 8;                            // 16-byte vectors per pixel / weight row
 
     // item = (cg, n, tile); a workgroup owns a contiguous range of items of ONE cg when possible (weights reloaded
     // only when cg changes)
