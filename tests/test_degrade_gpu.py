@@ -303,3 +303,17 @@ def test_full_size_properties(mode, gpu_device):
     # (5) mass: with replicate padding and a normalised kernel the global mean is preserved up to border effects
     if mode != "vb":
         assert abs(float(ox.double().mean()) / float(x.double().mean()) - 1) < 1e-3
+
+
+def test_c_abi_demo_without_torch(gpu_device):
+    """examples/c_abi_demo.cpp: a plain C++/HIP program (no torch) drives kmsr_degrade_f32 through include/kmsr.h and
+    checks V-A against its own host loop; built by __graft_entry__.build() (make demo)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kernel-modeling-super-resolution_amd",
+                       "c_abi_demo")
+    if not os.path.exists(exe):
+        pytest.skip("c_abi_demo not built (run __graft_entry__.build())")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "max rel err" in r.stdout and "bad descriptor -> rc -" in r.stdout      # error code + message, no abort
