@@ -105,6 +105,9 @@ WINOD_CASES = [
     (1, 100, 9, 132, 70, True, False, False, False),    # Cin / Cout not multiples of 8 / 64, 3 column tiles
     (1, 20, 3, 4, 32, True, True, False, True),         # 3x4 image: most lanes outside the image, + PixelShuffle
     (1, 8, 70, 128, 64, True, False, True, False),      # a single chunk (no prefetch), many row tiles
+    (3, 24, 1, 8, 64, True, True, False, False),        # one image row, three chunks (exactly the prefetch depth), batch 3
+    (2, 40, 5, 12, 96, False, False, True, False),      # five chunks, two cout groups, W = 12, residual without bias
+    (1, 64, 130, 68, 128, True, True, False, True),     # two column tiles with a 4-wide remainder + PixelShuffle
 ]
 
 
