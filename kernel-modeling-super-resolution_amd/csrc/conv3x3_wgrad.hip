@@ -35,9 +35,9 @@ struct WgradParams {
     int nblk;                             // persistent workgroups per (co group, ci group)
 };
 
-__global__ void __launch_bounds__(256, 1) conv3x3_wgrad_kernel(const float* __restrict__ xg, const float* __restrict__ dyg,
+__global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(const float* __restrict__ xg, const float* __restrict__ dyg,
                                                                float* __restrict__ partial, WgradParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE_F];
+    __shared__ __attribute__((aligned(16))) float lds[STAGE_F];   // ONE stage (52 KB): two workgroups per CU
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = wv & 1, ib = wv >> 1;
@@ -50,8 +50,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_kernel(const float* __re
     //   dy : thread = (px = tid & 63, co_sub = tid >> 6)          -> 16 loads, co = 4q + co_sub
     //   x  : thread = (pos = tid & 127, ci_sub = tid >> 7)        -> 32 loads, ci = 2q + ci_sub   (positions 0..127)
     //        + 2 loads for the last 8 halo positions 128..135:       e = tid + 256 j -> pos = 128 + (e & 7), ci = e >> 3
-    const int dpx = tid & 63, dcs = tid >> 6, dr = dpx / WC, dc = dpx % WC;
-    const int xpos = tid & 127, xcs = tid >> 7, xrr = xpos / XC, xcc = xpos % XC;
+    // dcs / xcs are wave-uniform (tid >> 6 is the wave id): told to the compiler so the channel part of every address is scalar
+    const int dpx = tid & 63, dcs = __builtin_amdgcn_readfirstlane(tid >> 6), dr = dpx / WC, dc = dpx % WC;
+    const int xpos = tid & 127, xcs = __builtin_amdgcn_readfirstlane(tid >> 7), xrr = xpos / XC, xcc = xpos % XC;
     int tpos[2], tci[2], trr[2], tcc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -97,8 +98,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_kernel(const float* __re
             }
         }
     };
-    auto store_stage = [&](int b) {
-        float* dl = lds + b * STAGE_F;
+    auto store_stage = [&]() {
+        float* dl = lds;
         float* xl = dl + DYF;
 #pragma unroll
         for (int q = 0; q < NDY; ++q) dl[dpx * PCH + 4 * q + dcs] = dyr[q];      // [px][co]
@@ -114,17 +115,20 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // A lone wave cannot keep a SIMD's fp32 matrix pipe full (measured: ~65 % busy with 9 independent accumulators), so the
+    // kernel runs TWO workgroups per CU (one wave of each per SIMD).  That leaves one 52 KB stage buffer per workgroup: the
+    // next stage is fetched into registers during the products and written after a barrier; the other workgroup's waves own
+    // the matrix pipes meanwhile.
     int s = blockIdx.x;
     if (s < total) {
         load_stage(s);
-        store_stage(0);
+        store_stage();
     }
     __syncthreads();
-    int b = 0;
     for (; s < total; s += p.nblk) {
         const bool more = s + p.nblk < total;
         if (more) load_stage(s + p.nblk);                                       // in flight under the 288 MFMAs below
-        const float* dl = lds + b * STAGE_F;
+        const float* dl = lds;
         const float* ap = dl + half * PCH + cb * 32 + l32;                      // + px*PCH
         const float* bp = dl + DYF + half * PCH + ib * 32 + l32;                // + pos*PCH
 #pragma unroll
@@ -139,9 +143,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_kernel(const float* __re
                 }
             }
         }
-        if (more) store_stage(b ^ 1);
+        __syncthreads();                                                        // every wave is done reading the stage
+        if (more) store_stage();
         __syncthreads();
-        b ^= 1;
     }
     // partial[(grp*nblk + blockIdx.x)][tap][co 64][ci 64]
     float* out = partial + ((long long)grp * p.nblk + blockIdx.x) * (9 * 64 * 64);
@@ -162,14 +166,22 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, float*
     const int ci = idx % Cin, tap = (idx / Cin) % 9, co = idx / (Cin * 9);
     const int grp = (co / 64) * cigs + ci / 64;
     const float* src = partial + (long long)grp * nblk * (9 * 64 * 64) + (tap * 64 + co % 64) * 64 + ci % 64;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += src[(long long)b * (9 * 64 * 64)];
+    // fixed summation order (8 interleaved running sums, combined pairwise): bit-reproducible, and the 8 loads of a round are
+    // independent so the loop does not serialise on memory latency
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 8 <= nblk; b += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a8[q] += src[(long long)(b + q) * (9 * 64 * 64)];
+    }
+    for (int q = 0; b < nblk; ++b, ++q) a8[q] += src[(long long)b * (9 * 64 * 64)];
+    const float s = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     dw[((long long)co * Cin + ci) * 9 + tap] = s;
 }
 
 int wgrad_blocks(const kmsr_conv3x3_desc* d) {
     const long long stages = (long long)d->N * ceil_div(d->H, WR) * ceil_div(d->W, WC);
-    return (int)std::min<long long>(stages, 256);   // one persistent workgroup per CU (52 KB x 2 LDS, 1 wave per SIMD)
+    return (int)std::min<long long>(stages, 512);   // two persistent workgroups per CU (52 KB of LDS each, 2 waves per SIMD)
 }
 
 }  // namespace
