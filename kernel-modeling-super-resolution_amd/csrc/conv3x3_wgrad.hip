@@ -35,6 +35,7 @@ struct WgradParams {
     int nblk;                             // persistent workgroups per (co group, ci group)
 };
 
+template <bool SMALL_M>     // SMALL_M: Cout <= 32 (one co block), the co-block wave pair splits the pixels instead
 __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(const float* __restrict__ xg, const float* __restrict__ dyg,
                                                                float* __restrict__ partial, WgradParams p) {
     __shared__ __attribute__((aligned(16))) float lds[STAGE_F];   // ONE stage (52 KB): two workgroups per CU
@@ -109,6 +110,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(const float* __re
         for (int j = 0; j < 2; ++j) xl[tpos[j] * PCH + tci[j]] = xt[j];
     };
 
+    // <= 32 output channels in this group (the SR tail: 3..7): the second 32-row co block would multiply zeros, so the two
+    // waves of a (co block) pair instead split the stage's pixel pairs (even / odd) over the SAME 32 channels; wave cb = 1
+    // still writes its slab into rows 32..63 and reduce_partials_kernel adds the two halves.
+    constexpr bool small_m = SMALL_M;
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -129,12 +134,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(const float* __re
         const bool more = s + p.nblk < total;
         if (more) load_stage(s + p.nblk);                                       // in flight under the 288 MFMAs below
         const float* dl = lds;
-        const float* ap = dl + half * PCH + cb * 32 + l32;                      // + px*PCH
+        const float* ap = dl + half * PCH + (small_m ? 0 : cb * 32) + l32;      // + px*PCH
         const float* bp = dl + DYF + half * PCH + ib * 32 + l32;                // + pos*PCH
 #pragma unroll
         for (int r = 0; r < WR; ++r) {
 #pragma unroll 4
             for (int c = 0; c < WC / 2; ++c) {
+                if constexpr (SMALL_M) {
+                    if ((c & 1) != cb) continue;                                // <= 32 output channels: the co-block pair splits the pixels
+                }
                 const float a = ap[(r * WC + 2 * c) * PCH];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
@@ -166,6 +174,7 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, float*
     const int ci = idx % Cin, tap = (idx / Cin) % 9, co = idx / (Cin * 9);
     const int grp = (co / 64) * cigs + ci / 64;
     const float* src = partial + (long long)grp * nblk * (9 * 64 * 64) + (tap * 64 + co % 64) * 64 + ci % 64;
+    const bool small_m = Cout <= 32;                         // pixel-split slabs: rows co and co + 32 hold the two halves
     // fixed summation order (8 interleaved running sums, combined pairwise): bit-reproducible, and the 8 loads of a round are
     // independent so the loop does not serialise on memory latency
     float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -175,7 +184,18 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, float*
         for (int q = 0; q < 8; ++q) a8[q] += src[(long long)(b + q) * (9 * 64 * 64)];
     }
     for (int q = 0; b < nblk; ++b, ++q) a8[q] += src[(long long)b * (9 * 64 * 64)];
-    const float s = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    float s = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    if (small_m) {
+        const float* src2 = src + 32 * 64;
+        float c8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b2 = 0;
+        for (; b2 + 8 <= nblk; b2 += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) c8[q] += src2[(long long)(b2 + q) * (9 * 64 * 64)];
+        }
+        for (int q = 0; b2 < nblk; ++b2, ++q) c8[q] += src2[(long long)b2 * (9 * 64 * 64)];
+        s += ((c8[0] + c8[1]) + (c8[2] + c8[3])) + ((c8[4] + c8[5]) + (c8[6] + c8[7]));
+    }
     dw[((long long)co * Cin + ci) * 9 + tap] = s;
 }
 
@@ -209,7 +229,10 @@ extern "C" int kmsr_conv3x3_wgrad_f32(const kmsr_conv3x3_desc* d, const float* x
     p.cogs = ceil_div(d->Cout, 64); p.cigs = ceil_div(d->Cin, 64);
     p.nblk = wgrad_blocks(d);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    conv3x3_wgrad_kernel<<<dim3(p.nblk, p.cogs * p.cigs), 256, 0, stream>>>(x, dy, static_cast<float*>(workspace), p);
+    if (d->Cout <= 32)
+        conv3x3_wgrad_kernel<true><<<dim3(p.nblk, p.cogs * p.cigs), 256, 0, stream>>>(x, dy, static_cast<float*>(workspace), p);
+    else
+        conv3x3_wgrad_kernel<false><<<dim3(p.nblk, p.cogs * p.cigs), 256, 0, stream>>>(x, dy, static_cast<float*>(workspace), p);
     KMSR_HIP_CHECK(hipGetLastError());
     const int total = d->Cout * d->Cin * 9;
     reduce_partials_kernel<<<ceil_div(total, 256), 256, 0, stream>>>(static_cast<const float*>(workspace), dw, d->Cin,
