@@ -199,6 +199,141 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, float*
     dw[((long long)co * Cin + ci) * 9 + tap] = s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Few output channels (Cout <= 7: the SR tail F -> bands).  The 64 x 64 x 9 slab above would be 90 % zero padding, so the
+// GEMM is turned around: the (co, tap) pairs -- at most 63 -- become the N dimension and the SHIFT moves from x to dy:
+//   dW[(co,u,v), ci] = sum_q x[ci, q] * dy[co, q - (u-1, v-1)]        (q runs over the x pixels; dy is 0 outside the image)
+//   A = x  (lane l: A[m = ci = l&31 (+32 mb)][k = q pair half]),  B = shifted dy (lane l: B[k][n = (co,tap) = l&31 (+32 nb)])
+// Workgroup = 4 waves = (ci block mb, n block nb): ONE accumulator tile per wave, one MFMA per wave and pixel pair; the x
+// stage (64 pixels x 64 channels, transposed, no halo) streams through LDS double buffered -- the kernel is bound by reading
+// x once (HBM), not by the matrix pipe.  Slab per workgroup: [n 64][ci 64]; reduced in a fixed order like the big kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int SD_ROWS = WR + 2, SD_COLS = WC + 2, SD_POS = SD_ROWS * SD_COLS;   // dy halo tile 4 x 34
+constexpr int SD_P = 9;                                                          // pitch of one dy position (co <= 7), odd
+constexpr int SX_F = WPX * PCH;                                                  // x stage [px][ci], pitch 65
+constexpr int SS_F = SX_F + SD_POS * SD_P;
+
+__global__ void __launch_bounds__(256, 2) conv3x3_wgrad_smallco_kernel(const float* __restrict__ xg, const float* __restrict__ dyg,
+                                                                       float* __restrict__ partial, WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * SS_F];
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mb = wv & 1, nb = wv >> 1;
+    const int cig = blockIdx.y;
+    const int H = p.H, W = p.W, Cout = p.Cout;
+    const long long HW = (long long)H * W;
+    const int total = p.N * p.n_stages;
+    const int ci_left = p.Cin - cig * 64;
+
+    // staging maps: x: thread = (px = tid & 63, sub = wave id) -> channels 4 q + sub, q < 16;
+    //               dy halo: element e = tid + 256 j -> (pos = e / Cout, co = e % Cout), e < 136 * Cout (<= 952 -> 4 loads)
+    const int dpx = tid & 63, sub = wv, dr = dpx / WC, dc = dpx % WC;
+    constexpr int NDYL = (SD_POS * 7 + 255) / 256;
+    float xr[16], dyr[NDYL];
+    auto load_stage = [&](int s) {
+        const int n = s / p.n_stages, t = s % p.n_stages;
+        const int y0 = (t / p.tiles_x) * WR, x0 = (t % p.tiles_x) * WC;
+        const float* __restrict__ xn = xg + ((long long)n * p.Cin + cig * 64) * HW;
+        const float* __restrict__ dyn = dyg + (long long)n * Cout * HW;
+        {
+            const int y = y0 + dr, x = x0 + dc;
+            const bool pok = y < H && x < W;
+            const long long poff = pok ? (long long)y * W + x : 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int ci = 4 * q + sub;
+                const bool ok = pok && ci < ci_left;
+                const float v = xn[ok ? ci * HW + poff : 0];
+                xr[q] = ok ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NDYL; ++j) {
+            const int e = tid + 256 * j;
+            const int pos = e / Cout, co = e - pos * Cout;
+            const int y = y0 - 1 + pos / SD_COLS, x = x0 - 1 + pos % SD_COLS;
+            const bool ok = e < SD_POS * Cout && y >= 0 && y < H && x >= 0 && x < W;
+            const float v = dyn[ok ? co * HW + (long long)y * W + x : 0];
+            dyr[j] = ok ? v : 0.f;
+        }
+    };
+    auto store_stage = [&](int b) {
+        float* xl = lds + b * SS_F;
+        float* dl = xl + SX_F;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xl[dpx * PCH + 4 * q + sub] = xr[q];        // [px][ci]
+#pragma unroll
+        for (int j = 0; j < NDYL; ++j) {
+            const int e = tid + 256 * j;
+            const int pos = e / Cout, co = e - pos * Cout;
+            if (e < SD_POS * Cout) dl[pos * SD_P + co] = dyr[j];                  // [pos][co]
+        }
+    };
+
+    // this lane's B column: n = 32 nb + l32 = co * 9 + tap; the dy position of x pixel (r, c) is (r + 2 - u, c + 2 - v) in the halo tile
+    const int ncol = 32 * nb + l32;
+    const bool nok = ncol < Cout * 9;
+    const int nco = nok ? ncol / 9 : 0, ntap = nok ? ncol % 9 : 0;
+    const int boffs = ((2 - ntap / 3) * SD_COLS + (2 - ntap % 3)) * SD_P + nco;   // + (r * SD_COLS + c) * SD_P
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    int s = blockIdx.x;
+    if (s < total) {
+        load_stage(s);
+        store_stage(0);
+    }
+    __syncthreads();
+    int b = 0;
+    for (; s < total; s += p.nblk) {
+        const bool more = s + p.nblk < total;
+        if (more) load_stage(s + p.nblk);
+        const float* xl = lds + b * SS_F;
+        const float* ap = xl + half * PCH + mb * 32 + l32;                       // + px * PCH
+        const float* bp = xl + SX_F + boffs + half * SD_P;                       // + (r * SD_COLS + c) * SD_P
+#pragma unroll
+        for (int r = 0; r < WR; ++r) {
+#pragma unroll
+            for (int c = 0; c < WC / 2; ++c) {
+                const float a = ap[(r * WC + 2 * c) * PCH];
+                const float bv = nok ? bp[(r * SD_COLS + 2 * c) * SD_P] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+            }
+        }
+        if (more) store_stage(b ^ 1);
+        __syncthreads();
+        b ^= 1;
+    }
+    // partial[(cig * nblk + blockIdx.x)][n 64][ci 64]; D lane l holds column n = l&31 and rows ci = (reg&3) + 8 (reg>>2) + 4 (l>>5)
+    float* out = partial + ((long long)cig * p.nblk + blockIdx.x) * (64 * 64);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ci = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        out[(32 * nb + l32) * 64 + ci] = acc[r];
+    }
+}
+
+// dw[co][ci][tap] = sum_blk partial[cig][blk][co*9+tap][ci%64]   (fixed order, 8 interleaved running sums)
+__global__ void reduce_partials_smallco_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cin, int Cout,
+                                               int nblk) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over Cout*9*Cin, ci fastest
+    if (idx >= Cout * 9 * Cin) return;
+    const int ci = idx % Cin, n = idx / Cin, co = n / 9, tap = n % 9;
+    const float* src = partial + (long long)(ci / 64) * nblk * (64 * 64) + n * 64 + ci % 64;
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 8 <= nblk; b += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a8[q] += src[(long long)(b + q) * (64 * 64)];
+    }
+    for (int q = 0; b < nblk; ++b, ++q) a8[q] += src[(long long)b * (64 * 64)];
+    dw[((long long)co * Cin + ci) * 9 + tap] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+}
+
+constexpr int kWgradSmallCo = 7;
+
 int wgrad_blocks(const kmsr_conv3x3_desc* d) {
     const long long stages = (long long)d->N * ceil_div(d->H, WR) * ceil_div(d->W, WC);
     return (int)std::min<long long>(stages, 512);   // two persistent workgroups per CU (52 KB of LDS each, 2 waves per SIMD)
@@ -229,6 +364,15 @@ extern "C" int kmsr_conv3x3_wgrad_f32(const kmsr_conv3x3_desc* d, const float* x
     p.cogs = ceil_div(d->Cout, 64); p.cigs = ceil_div(d->Cin, 64);
     p.nblk = wgrad_blocks(d);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (d->Cout <= kWgradSmallCo) {
+        conv3x3_wgrad_smallco_kernel<<<dim3(p.nblk, p.cigs), 256, 0, stream>>>(x, dy, static_cast<float*>(workspace), p);
+        KMSR_HIP_CHECK(hipGetLastError());
+        const int tot = d->Cout * d->Cin * 9;
+        reduce_partials_smallco_kernel<<<ceil_div(tot, 256), 256, 0, stream>>>(static_cast<const float*>(workspace), dw, d->Cin,
+                                                                               d->Cout, p.nblk);
+        KMSR_HIP_CHECK(hipGetLastError());
+        return KMSR_OK;
+    }
     if (d->Cout <= 32)
         conv3x3_wgrad_kernel<true><<<dim3(p.nblk, p.cogs * p.cigs), 256, 0, stream>>>(x, dy, static_cast<float*>(workspace), p);
     else

@@ -17,7 +17,8 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("N,Cin,H,W,Cout", [(2, 64, 20, 40, 64), (1, 3, 17, 33, 64), (2, 64, 16, 32, 3), (1, 64, 9, 70, 256),
-                                            (3, 20, 7, 5, 12), (1, 130, 6, 34, 70)])
+                                            (3, 20, 7, 5, 12), (1, 130, 6, 34, 70),
+                                            (2, 64, 33, 45, 5), (1, 100, 5, 70, 7), (1, 8, 1, 1, 1), (2, 64, 6, 64, 20)])   # small-Cout kernels (<= 7, <= 32)
 def test_wgrad_and_dgrad_vs_torch(N, Cin, H, W, Cout, gpu_device):
     g = torch.Generator().manual_seed(N + Cin + Cout)
     x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
