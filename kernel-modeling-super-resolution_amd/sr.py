@@ -170,7 +170,7 @@ class Conv3x3Function(torch.autograd.Function):
             g = torch.nn.functional.pixel_unshuffle(g, 2)     # gradient in the conv-output layout
         g = g.contiguous()
         if ctx.relu:
-            g = g * (y > 0)
+            g = torch.ops.aten.threshold_backward(g, y, 0.0)      # g where y > 0 else 0, one pass (no mask tensor)
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             # data gradient = the same convolution with w'[ci,co,u,v] = w[co,ci,2-u,2-v]
