@@ -184,6 +184,35 @@ class Conv3x3Function(torch.autograd.Function):
         return dx, dw, db, None, dres, None
 
 
+class ResBlockFunction(torch.autograd.Function):
+    """y = h + conv2(relu(conv1(h))) as ONE autograd node (HIP kernels in both directions).  Besides the fused forward
+    epilogues this lets the backward add the skip path's gradient inside the data-gradient kernel of conv1
+    (dh = dgrad1(dt) + g as that launch's residual) instead of a separate accumulation pass per block."""
+
+    @staticmethod
+    def forward(ctx, h, w1, b1, w2, b2):
+        h = h.contiguous()
+        t = Conv3x3Function._run(h, w1.detach(), b1, True)
+        y = Conv3x3Function._run(t, w2.detach(), b2, False, residual=h)
+        ctx.save_for_backward(h, t, w1, w2)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        h, t, w1, w2 = ctx.saved_tensors
+        g = g.contiguous()
+        flipT = lambda w: w.detach().flip(2, 3).transpose(0, 1).contiguous()
+        dw2 = conv3x3_wgrad(t, g) if ctx.needs_input_grad[3] else None
+        db2 = g.sum(dim=(0, 2, 3)) if ctx.has_bias[1] and ctx.needs_input_grad[4] else None
+        dt = Conv3x3Function._run(g, flipT(w2), None, False)
+        dt = torch.ops.aten.threshold_backward(dt, t, 0.0)
+        dw1 = conv3x3_wgrad(h, dt) if ctx.needs_input_grad[1] else None
+        db1 = dt.sum(dim=(0, 2, 3)) if ctx.has_bias[0] and ctx.needs_input_grad[2] else None
+        dh = Conv3x3Function._run(dt, flipT(w1), None, False, residual=g) if ctx.needs_input_grad[0] else None
+        return dh, dw1, db1, dw2, db2
+
+
 class _PackCache:
     """Packed weights of one nn.Conv2d, rebuilt when the parameter is modified in place or replaced."""
 
@@ -380,7 +409,7 @@ class SRNet(nn.Module):
         f = cv(self.head, x)
         h = f
         for blk in self.body:
-            h = cv(blk.conv2, cv(blk.conv1, h, True), residual=h)
+            h = ResBlockFunction.apply(h, blk.conv1.weight, blk.conv1.bias, blk.conv2.weight, blk.conv2.bias)
         h = cv(self.body_tail, h, residual=f)
         for up in self.up:
             h = cv(up, h, ps=True)
