@@ -43,6 +43,33 @@ def host_cores():
     return n
 
 
+def static_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel cannot be counted inside this process: they come from the committed
+    rocprofv3 PMC passes of this same command (tools/pmc_traffic.sh -> profiles/r0N_bench_pmc_traffic.json; FETCH_SIZE x2
+    + WRITE_SIZE, separate passes).  Marked static, with the file and the source hash of the kernel it was taken on; null
+    when the kernel source has changed since (no silently stale number)."""
+    import glob
+    import hashlib
+    prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic.json")))
+    out = {"traffic": None, "traffic_static": True, "traffic_source": None}
+    for path in reversed(prof):
+        try:
+            with open(path) as f:
+                pm = json.load(f)
+            src = os.path.join(ROOT, "kernel-modeling-super-resolution_amd", "csrc", pm["kernel_source"])
+            with open(src, "rb") as f:
+                sha = hashlib.sha256(f.read()).hexdigest()[:16]
+            if kernel_key in pm["kernel"] and sha == pm["kernel_source_sha256_16"]:
+                out["traffic"] = pm["traffic_bytes_per_launch"]
+                out["traffic_source"] = f"profiles/{os.path.basename(path)} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; " \
+                                        f"recorded, not measured in this run; kernel source sha256 {sha} matches)"
+                out["traffic_over_algorithmic_bytes"] = pm.get("traffic_over_algorithmic")
+                break
+        except (OSError, KeyError, ValueError):
+            continue
+    return out
+
+
 def synth_hr(n, c, h, w, device, seed):
     """Synthetic 'Landsat-shaped' TOA radiance tiles: U(20,100), fp32, NaN-free."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -124,8 +151,9 @@ class DegradeSRWorkload:
     name = "degrade+sr_fwd_x4_lr256_c3_b16"
 
     def __init__(self, device, rank, batch=16, C=3, h=256, w=256):
-        from kmsr_amd.sr import SRNet
+        from kmsr_amd.sr import SRNet, pick_algo
         self.B, self.C, self.H, self.W = batch, C, 4 * h, 4 * w
+        self.h, self.w = h, w
         self.hr = synth_hr(batch, C, self.H, self.W, device, seed=2000 + rank)
         bank, sigma = moe_bank(device)
         self.bank, self.sigma = bank[:, :C].contiguous(), sigma[:, :C].contiguous()
@@ -139,12 +167,18 @@ class DegradeSRWorkload:
         self.taps_ready = False
         self.patches_per_step = batch
         self.flops_per_patch = self.net.flops_per_lr_pixel() * h * w
-        # dominant kernel: the 33 conv3x3 64->64 launches of the residual body (61 % of the step's FLOPs).  Its roofline is
-        # quoted on ALGORITHMIC FLOPs (2*9*N*Cin*Cout*H*W) against the dense fp32 MFMA peak; the Winograd
-        # kernel issues 2.25x fewer MFMA FLOPs than that, so `frac` can approach / exceed what a direct conv could reach.
+        # dominant kernel: the 33 conv3x3 64->64 launches of the residual body (61 % of the step's FLOPs).
+        #   algorithmic FLOPs per launch = 2*9*N*Cin*Cout*H*W;
+        #   ISSUED MFMA FLOPs per launch = what the kernel's v_mfma instructions execute: the Winograd F(2x2,3x3) kernels
+        #   need 16 multiplies per 2x2 output tile and (ci, co) pair instead of 36 -> algorithmic / 2.25 at this shape
+        #   (no channel / tile padding: 64 channels, 256 % 64 == 0).  roofline.frac is issued / peak: <= 1 by construction.
+        self.body_algo = pick_algo(64, 64, 1, w, self.net.use_winograd)
         self.body_flops_per_launch = 2.0 * 9 * batch * 64 * 64 * h * w
-        self.body_ms, self.body_launches = 0.0, 0
-        self._events = []
+        self.body_issue_ratio = {"direct": 1.0, "winograd": 1 / 2.25, "winograd_dma": 1 / 2.25}[self.body_algo]
+        # degradation kernel: algorithmic bytes per patch = HR read once + LR written once + taps
+        self.deg_bytes_per_launch = batch * (4 * C * self.H * self.W + 4 * C * h * w + 4 * C * 13 * 13)
+        self._record = False
+        self._ev_body, self._ev_deg = [], []
 
     def _timed_conv(self, name, conv, x, **kw):
         """Body convs are bracketed with HIP events on the launch stream (torch's current stream)."""
@@ -153,7 +187,7 @@ class DegradeSRWorkload:
             e0.record()
             out = self._orig_conv(name, conv, x, **kw)
             e1.record()
-            self._events.append((e0, e1))
+            self._ev_body.append((e0, e1))
             return out
         return self._orig_conv(name, conv, x, **kw)
 
@@ -164,45 +198,73 @@ class DegradeSRWorkload:
         self._record = on
 
     def step(self):
+        if self._record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         kmsr_amd.degrade_batch(self.hr, self.bank, 4, down="stride", pad="zero", normalize=False,
                                kernel_idx=self.kid, sigma=self.sigma, noise="gaussian", seed=42, offset=self.step_no,
                                out=self.lr, workspace=self.ws, taps_ready=self.taps_ready, flags=L.FLAG_FORCE_FAST)
+        if self._record:
+            e1.record()
+            self._ev_deg.append((e0, e1))
         self.taps_ready = True
         self.step_no += 1
         self.sr = self.net(self.lr)
 
     def roofline(self, _unused_ms):
-        ms = [a.elapsed_time(b) for a, b in self._events]
+        ms = [a.elapsed_time(b) for a, b in self._ev_body]
         kernel_ms = sum(ms) / max(len(ms), 1)
-        achieved = self.body_flops_per_launch / (kernel_ms * 1e-3) / 1e12
-        # HBM bytes per launch of this kernel cannot be counted inside this process: they come from the committed PMC passes
-        # of this same command (tools/pmc_traffic.sh -> profiles/r01_bench_pmc_traffic.json), null if that file is absent
-        traffic, src = None, None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_pmc_traffic.json")) as f:
-                pm = json.load(f)
-            traffic, src = pm["traffic_bytes_per_launch"], "profiles/r01_bench_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
-        except (OSError, KeyError, ValueError):
-            pass
-        return {"bound": "mfma", "kernel": "conv3x3_winod_kernel<false> (3x3 conv 64->64 @256x256, batch 16; Winograd F(2x2,3x3) on fp32 MFMA, LDS-DMA staged; "
-                                           "33 launches/step; achieved = direct-conv algorithmic FLOPs / time)",
-                "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
-                "algorithmic_flops_per_launch": self.body_flops_per_launch, "kernel_ms": round(kernel_ms, 4),
-                # the Winograd kernel ISSUES 2.25x fewer MFMA flops than the algorithmic (direct-conv) count, which is why
-                # `frac` can exceed 1; the matrix pipe's own utilisation is reported beside it
-                "mfma_issued_tflops": round(achieved / 2.25, 2), "mfma_pipe_frac": round(achieved / 2.25 / F32_MFMA_PEAK_TFLOPS, 4),
-                "launches_timed": len(ms),
-                "step_tflops": None}
+        algorithmic = self.body_flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        issued = algorithmic * self.body_issue_ratio
+        traffic = static_traffic("conv3x3_winod")
+        kname = {"winograd_dma": "conv3x3_winod_kernel<false>", "winograd": "conv3x3_wino_kernel<false>",
+                 "direct": "conv3x3_mfma_kernel<1,false>"}[self.body_algo]
+        out = {"bound": "mfma",
+               "kernel": f"{kname} (3x3 conv 64->64 @256x256, batch 16; 33 launches/step; Winograd F(2x2,3x3) on the fp32 MFMA, LDS-DMA staged)",
+               "achieved": round(issued, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": round(issued / F32_MFMA_PEAK_TFLOPS, 4),
+               "what": "achieved = MFMA FLOPs the kernel ISSUES per launch (algorithmic direct-conv FLOPs / 2.25 for Winograd F(2x2,3x3)) "
+                       "/ mean launch duration (HIP events on the launch stream, instrumented pass of the same steps); frac = matrix-pipe utilisation",
+               "issued_flops_per_launch": self.body_flops_per_launch * self.body_issue_ratio,
+               "algorithmic_flops_per_launch": self.body_flops_per_launch,
+               "algorithmic_tflops": round(algorithmic, 2),
+               "algorithmic_over_peak": round(algorithmic / F32_MFMA_PEAK_TFLOPS, 4),
+               "kernel_ms": round(kernel_ms, 4), "launches_timed": len(ms)}
+        out.update(traffic)
+        return out
 
-    def cpu_baseline(self, budget_s=20.0):
+    def issued_mfma_flops_per_step(self, fused):
+        """MFMA FLOPs one step issues (the degradation and the 64->3 tail are VALU kernels and not counted):
+        Winograd layers = algorithmic / 2.25; head = direct MFMA with the 3 bands padded to one 8-channel chunk;
+        collapsed upsampler = one 5x5 conv 64 -> 48 (padded to 64) per LR pixel (+ the frame strips, < 2 % of it, not counted)."""
+        px = self.B * self.h * self.w
+        body = 33 * 18.0 * 64 * 64 / 2.25
+        head = 18.0 * 8 * 64
+        up = 50.0 * 64 * 64 if fused else 18.0 * 64 * 256 * (1 + 4) / 2.25
+        return (body + head + up) * px
+
+    def roofline_degrade(self):
+        """north_star's first target: HBM roofline of the fused degradation kernel, from the launches inside the steps."""
+        ms = [a.elapsed_time(b) for a, b in self._ev_deg]
+        if not ms:
+            return None
+        kernel_ms = sum(ms) / len(ms)
+        ach = self.deg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "degrade_rowstream_kernel (V-B: 13x13 stride 4, zero pad, Philox noise) on HR [16,3,1024,1024]",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": None, "algorithmic_bytes_per_launch": self.deg_bytes_per_launch,
+                "kernel_ms": round(kernel_ms, 4), "launches_timed": len(ms),
+                "what": "HIP events around the kmsr_degrade_f32 call of every instrumented step (tap table already built)"}
+
+    def cpu_baseline(self, budget_s=10.0):
         """Same step on the host cores: oracle degradation (C restatement, OpenMP) + the stock-torch SR oracle module
-        (ATen CPU convs -- the way the reference itself runs its conv stacks on a CPU), 1 patch at a time."""
+        (ATen CPU convs -- the way the reference itself runs its conv stacks on a CPU), 1 patch at a time; at all cores
+        (`value`) and at one thread; plus the degradation alone in both CPU forms SURVEY 8(d) names (C restatement and
+        the reference's own F.conv2d form, oracle/torch_ops.py), 1 thread and all cores."""
         import oracle
         from oracle.sr_torch import SRNetTorch
+        from oracle.torch_ops import vb_torch
         cores = host_cores()
-        oracle.set_threads(cores)
-        torch.set_num_threads(cores)
         ref = SRNetTorch(self.C, 64, 16, 4).eval()
         ref.load_state_dict({k: v.cpu() for k, v in self.net.state_dict().items()})
         hr = self.hr[:1].cpu().numpy()
@@ -214,15 +276,35 @@ class DegradeSRWorkload:
             lr = oracle.add_gaussian_noise(clean, sig, seed=42, offset=0)
             with torch.no_grad():
                 return ref(torch.from_numpy(lr))
-        one()
+
+        def rate(fn, budget, nmax):
+            fn()
+            t0 = time.perf_counter()
+            n = 0
+            while True:
+                fn()
+                n += 1
+                el = time.perf_counter() - t0
+                if el > budget or n >= nmax:
+                    return n / el, n, el
+
+        def threads(n):
+            oracle.set_threads(n)
+            torch.set_num_threads(n)
+
+        threads(cores)
+        v_all, n_all, el_all = rate(one, budget_s, 16)
+        hr_t, kern_t = torch.from_numpy(hr), torch.from_numpy(kern)
+        deg = {"unit": "LR patches/s", "shape": "HR 3x1024x1024 -> LR 3x256x256 (clean V-B part, no noise)"}
+        deg["oracle_c_all_cores"] = round(rate(lambda: oracle.vb_blur_stride(hr, kern, 4), 1.0, 200)[0], 2)
+        deg["torch_ops_all_cores"] = round(rate(lambda: vb_torch(hr_t, kern_t), 1.5, 200)[0], 2)
+        threads(1)
         t0 = time.perf_counter()
-        n = 0
-        while True:
-            one()
-            n += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or n >= 16:
-                break
+        one()
+        v_one = 1.0 / (time.perf_counter() - t0)
+        deg["oracle_c_1_thread"] = round(rate(lambda: oracle.vb_blur_stride(hr, kern, 4), 1.0, 200)[0], 2)
+        deg["torch_ops_1_thread"] = round(rate(lambda: vb_torch(hr_t, kern_t), 1.5, 200)[0], 2)
+        threads(cores)
         # the metric's second half, "PSNR delta vs ref": the same patch (same noise stream: seed 42, offset 0) through the
         # HIP path and through the oracle, PSNR of each against the HR patch (declared data range R = 100, the radiance
         # span of the synthetic tiles), and the largest relative difference of the two SR outputs
@@ -238,9 +320,11 @@ class DegradeSRWorkload:
             deltas[tag] = {"psnr_delta_db": round(psnr(sr_gpu, hr0, 100.0) - psnr(sr_cpu, hr0, 100.0), 7),
                            "max_rel_diff": float((sr_gpu - sr_cpu).abs().max() / sr_cpu.abs().max())}
         self.net.fuse_upsampler = False
-        return {"value": round(n / el, 3), "unit": "LR patches/s", "cores": cores, "kind": "port",
-                "sample": f"{n} patch(es): HR 3x1024x1024 -> LR 256^2 -> SR 1024^2, oracle C degradation + torch-CPU "
-                          f"SRNetTorch fp32, {el:.1f} s on {cores} threads",
+        return {"value": round(v_all, 3), "unit": "LR patches/s", "cores": cores, "kind": "port",
+                "sample": f"{n_all} patch(es): HR 3x1024x1024 -> LR 256^2 -> SR 1024^2, oracle C degradation + torch-CPU "
+                          f"SRNetTorch fp32, {el_all:.1f} s on {cores} threads",
+                "one_thread": {"value": round(v_one, 4), "cores": 1, "sample": "1 patch, same step, OMP / ATen threads = 1"},
+                "degrade_only": deg,
                 "psnr_vs_oracle": deltas}
 
 
@@ -310,11 +394,19 @@ class TrainWorkload:
         self.step_no, self.taps_ready = 0, False
         self.patches_per_step = batch
         self.fwd_flops_per_patch = self.net.flops_per_lr_pixel() * h * w
+        self.noise_seed = kd.rank_seed(42)       # every rank draws its own eps field (independent samples, like torch.randn_like per process)
+        # MFMA FLOPs the step ISSUES: forward and data gradient of the F->F / F->4F layers run the Winograd F(2x2,3x3)
+        # kernels (algorithmic / 2.25); head, tail and every weight gradient are direct
+        F_, Cc, nb = self.net.n_feats, C, len(self.net.body)
+        wino_px = 18.0 * ((2 * nb + 1) * F_ * F_ + F_ * 4 * F_ * (1 + 4))        # per LR pixel: body + body_tail + up1 + up2(at 2x)
+        direct_px = 18.0 * (Cc * F_ + F_ * Cc * 16)                                # head + tail (at 4x)
+        self.issued_flops_per_patch = (2 * wino_px / 2.25 + wino_px + 3 * direct_px) * h * w
+        assert abs((wino_px + direct_px) * h * w - self.fwd_flops_per_patch) < 1e-6 * self.fwd_flops_per_patch
 
     def step(self):
-        kid = torch.randint(0, 10, (self.B,), generator=self.gen, dtype=torch.int32).to(self.device)
+        kid = torch.randint(0, 10, (self.B,), generator=self.gen, dtype=torch.int32)     # host tensor: range-checked without a device sync
         kmsr_amd.degrade_batch(self.hr, self.bank, 4, down="stride", pad="zero", normalize=False, kernel_idx=kid,
-                               sigma=self.sigma, noise="gaussian", seed=42, offset=self.step_no, out=self.lr,
+                               sigma=self.sigma, noise="gaussian", seed=self.noise_seed, offset=self.step_no, out=self.lr,
                                workspace=self.ws, taps_ready=self.taps_ready, flags=L.FLAG_FORCE_FAST)
         self.taps_ready = True
         self.step_no += 1
@@ -326,10 +418,16 @@ class TrainWorkload:
         self.loss = loss
 
     def roofline(self, step_ms):
-        tf = 3.0 * self.fwd_flops_per_patch * self.B / (step_ms * 1e-3) / 1e12      # fwd + dgrad + wgrad
-        return {"bound": "mfma", "kernel": "whole training step (fwd + dgrad + wgrad conv3x3 kernels)", "achieved": round(tf, 2),
-                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "algorithmic_flops_per_step": 3.0 * self.fwd_flops_per_patch * self.B, "step_ms": round(step_ms, 3)}
+        alg = 3.0 * self.fwd_flops_per_patch * self.B / (step_ms * 1e-3) / 1e12      # fwd + dgrad + wgrad, direct-conv count
+        iss = self.issued_flops_per_patch * self.B / (step_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "whole training step (fwd + dgrad + wgrad conv3x3 kernels)", "achieved": round(iss, 2),
+                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(iss / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "what": "achieved = MFMA FLOPs ISSUED per step (Winograd forward / data-gradient layers count algorithmic / 2.25, "
+                        "weight gradients and head / tail direct) / step time -- includes every non-conv pass of the step",
+                "issued_flops_per_step": self.issued_flops_per_patch * self.B,
+                "algorithmic_flops_per_step": 3.0 * self.fwd_flops_per_patch * self.B,
+                "algorithmic_tflops": round(alg, 2), "algorithmic_over_peak": round(alg / F32_MFMA_PEAK_TFLOPS, 4),
+                "step_ms": round(step_ms, 3)}
 
 
 def main():
@@ -361,8 +459,6 @@ def main():
     wl = {"degrade_sr": DegradeSRWorkload, "degrade": DegradeWorkload, "train": TrainWorkload, "sr_bf16": SRBf16Workload}[args.workload](device, rank)
     for _ in range(max(args.warmup, 1)):
         wl.step()
-    if hasattr(wl, "instrument"):
-        wl.instrument(True)
 
     def timed(steps):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -384,12 +480,20 @@ def main():
         wl.net.fuse_upsampler = True
         for _ in range(2):
             wl.step()
+    # the headline: EXACTLY args.steps steps, no per-kernel instrumentation inside
     elapsed, kernel_ms = timed(args.steps)
+    instrumented = None
+    if hasattr(wl, "instrument"):
+        # per-kernel HIP events (launch stream) in a second pass of the same steps, right after the timed region: the
+        # headline carries no event records, the roofline numbers still come from live launches of this run
+        wl.instrument(True)
+        el_i, _ = timed(args.steps)
+        wl.instrument(False)
+        instrumented = round(el_i / args.steps * 1e3, 4)
     variants = None
     if args.workload == "degrade_sr" and not args.fuse_upsampler:
-        # same job with the upsampler collapsed (identical outputs within fp32 rounding, tests/test_conv_gpu.py); reported
+        # same job with the upsampler collapsed (identical outputs within fp32 rounding, tests/test_fullsize_gpu.py); reported
         # beside the headline, never as `value`
-        wl.instrument(False)
         wl.net.fuse_upsampler = True
         for _ in range(2):
             wl.step()
@@ -399,7 +503,9 @@ def main():
             "value": round(wl.patches_per_step * args.steps * world / el2, 2), "unit": "LR patches/s",
             "ms_per_step": round(el2 / args.steps * 1e3, 4),
             "what": "up1/PS/up2/PS/tail (linear) run as ONE conv5x5 64->48 + PixelShuffle(4) launch + exact 4-px frame strips; "
-                    "same SR output (max rel diff ~2e-6)"}}
+                    "same SR output (<= 2e-5 of scale at full size, tests/test_fullsize_gpu.py)",
+            "issued_mfma_flops_per_step": wl.issued_mfma_flops_per_step(True),
+            "issued_mfma_tflops": round(wl.issued_mfma_flops_per_step(True) * args.steps * world / el2 / 1e12, 2)}}
 
     if rank == 0:
         total_patches = wl.patches_per_step * args.steps * world
@@ -421,6 +527,15 @@ def main():
                        "sharding": f"independent patches, {wl.B}/GPU, no data-path collective"},
             "roofline": wl.roofline(kernel_ms),
         }
+        if hasattr(wl, "roofline_degrade"):
+            out["roofline_degrade"] = wl.roofline_degrade()
+        if instrumented is not None:
+            out["instrumented_ms_per_step"] = instrumented
+        if args.workload == "degrade_sr":
+            f = wl.issued_mfma_flops_per_step(args.fuse_upsampler)
+            out["step_mfma"] = {"issued_flops_per_step": f, "issued_tflops": round(f * args.steps * world / elapsed / 1e12, 2),
+                                "frac_of_peak": round(f * args.steps / elapsed / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                                "algorithmic_flops_per_step": wl.flops_per_patch * wl.B}
         if args.workload == "degrade_sr":
             out["config"]["upsampler"] = "collapsed conv5x5+PS4" if args.fuse_upsampler else "layer-by-layer"
         if variants:

@@ -12,12 +12,8 @@
 // issued before the current chunk's 144 MFMAs per wave and written to the other buffer after them, one
 // __syncthreads per chunk.  Two blocks per CU (2 waves per SIMD) overlap one block's barrier with the other's MFMAs.
 #include "kmsr_common.h"
-#ifndef KMSR_CONV_ABLATE
-#define KMSR_CONV_ABLATE 0  // diagnostic builds only: 1 = no global loads in the k-loop, 2 = no MFMA, 3 = no LDS restage
-#endif
 
 #include <algorithm>
-#include <cstdlib>
 
 namespace kmsr {
 namespace {
@@ -180,14 +176,10 @@ __global__ void __launch_bounds__(256, S == 1 ? 2 : 1) conv3x3_mfma_kernel(const
                 const float a1 = wb[aoff + (tap * CK + 2 * kp) * COB + 32];
                 const float b0 = inb[boff + (2 * kp) * (IH * IWP) + dy * IWP + dx];
                 const float b1 = inb[boff + (2 * kp) * (IH * IWP) + (S + dy) * IWP + dx];
-#if KMSR_CONV_ABLATE == 2
-                asm volatile("" ::"v"(a0), "v"(a1), "v"(b0), "v"(b1));
-#else
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-#endif
             }
         }
     };

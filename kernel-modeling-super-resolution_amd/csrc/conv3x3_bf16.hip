@@ -14,7 +14,6 @@
 #include "kmsr_common.h"
 
 #include <algorithm>
-#include <cstdlib>
 
 namespace kmsr {
 namespace {
@@ -289,8 +288,7 @@ extern "C" int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x, 
     const long long items = (long long)p.tiles * p.cgs * d->N;
     if (items > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv grid too large");
     p.n_items = (int)items;
-    int grid = (int)std::min<long long>(items, 256);
-    if (const char* e = getenv("KMSR_BF16_GRID")) grid = std::max(1, std::min((int)items, atoi(e)));
+    const int grid = (int)std::min<long long>(items, 256);
     const size_t shmem = bf16_lds_bytes(d->Cin);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const auto* xs = static_cast<const unsigned short*>(x);

@@ -14,9 +14,6 @@
 // (register staged, issued right after the first MFMAs) to land; they are transformed and written between two
 // barriers.  (A double-buffered 8-channel variant was slower: its 1.9 us phases are shorter than a global round trip.)
 #include "kmsr_common.h"
-#ifndef KMSR_WINO_ABLATE
-#define KMSR_WINO_ABLATE 0  // diagnostic builds: 1 no global loads in loop, 2 no MFMA, 3 no restage, 4 no epilogue stores
-#endif
 
 #include <algorithm>
 
@@ -183,25 +180,17 @@ __global__ void __launch_bounds__(kWinoThreads, 2) conv3x3_wino_kernel(const flo
         const bool more = chunk + 1 < p.nchunks;     // block-uniform
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-#if KMSR_WINO_ABLATE != 1 && KMSR_WINO_ABLATE != 3
             if (a == 1 && more) load_chunk(chunk + 1);       // one burst right after the first MFMAs: ~3.5 us to land
-#endif
 #pragma unroll
             for (int kp = 0; kp < WCK / 2; ++kp) {
                 const float av = ub[aoff + (a * WCK + 2 * kp) * WCO];
                 const float bv = vb[boff + (a * WCK + 2 * kp) * NT];
-#if KMSR_WINO_ABLATE == 2
-                asm volatile("" ::"v"(av), "v"(bv));
-#else
                 acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
-#endif
             }
         }
         __syncthreads();                                     // every wave has finished reading this chunk
         if (more) {
-#if KMSR_WINO_ABLATE != 3
             store_chunk();                                   // transform + restage the next chunk
-#endif
             __syncthreads();
         }
     }
@@ -236,9 +225,6 @@ __global__ void __launch_bounds__(kWinoThreads, 2) conv3x3_wino_kernel(const flo
         xch[(wv * 16 + reg) * 64 + lane] = send;
     }
     __syncthreads();
-#if KMSR_WINO_ABLATE == 4
-    if (p.relu != 12345) { if (tid == 0 && keep[0].x == 1.2345f) out[0] = keep[3].y; return; }
-#endif
     const int y = ty0 + 2 * tb + ih, x0 = tx0 + 2 * l32;     // this wave finalises output row `ih` of its tiles
     const bool pok2 = y < H && x0 < W;                        // (x0, x0+1) is an aligned pair: inside or outside as a whole
 #pragma unroll

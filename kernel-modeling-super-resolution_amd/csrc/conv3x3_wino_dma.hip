@@ -11,12 +11,8 @@
 // LDS: U 2 x 32 KB + raw 2 x 16 KB + V 32 KB = 128 KB; the epilogue's 64 KB exchange buffer aliases the U buffers.
 // Requires W % 4 == 0 and 16-byte aligned tensors (the register-staged kernel serves everything else).
 #include "kmsr_common.h"
-#ifndef KMSR_WINOD_ABLATE
-#define KMSR_WINOD_ABLATE 0
-#endif
 
 #include <algorithm>
-#include <cstdlib>
 
 namespace kmsr {
 namespace {
@@ -289,9 +285,6 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winod_kernel(const float*
         xch[(wv * 16 + reg) * 64 + lane] = send;
     }
     __syncthreads();
-#if KMSR_WINOD_ABLATE == 4
-    if (p.relu != 12345) { if (tid == 0 && keep[0].x == 1.2345f) out[0] = keep[3].y; return; }
-#endif
     const int y = ty0 + 2 * tb + ih, x0 = tx0 + 2 * l32;     // this wave finalises output row `ih` of its tiles
     const bool pok2 = y < H && x0 < W;                        // (x0, x0+1) is an aligned pair: inside or outside as a whole
 #pragma unroll
@@ -335,265 +328,6 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winod_kernel(const float*
     }
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// Persistent form: a workgroup walks a contiguous range of (image, cout group, tile) items and never drains its DMA
-// pipeline between them -- the chunk stream is global: while item T runs its last two MFMA phases the first two chunks
-// of item T+1 are already on their way into the U / raw buffers, so only T+1's first input transform (not a global
-// round trip) separates one item's epilogue from the next item's first MFMA.  The epilogue's 64 KB exchange buffer lives
-// in V + a spare 32 KB (U and raw hold the next item's data by then); the bias row sits in the raw buffer's unused tail.
-// ------------------------------------------------------------------------------------------------
-constexpr int P_OFF_U = 0, P_OFF_V = 2 * DUF, P_OFF_X = P_OFF_V + DVF, P_OFF_R = P_OFF_X + DVF;
-constexpr int P_LDS_FLOATS = P_OFF_R + 2 * RAWF;                 // 40960 floats = 160 KB
-constexpr int P_OFF_B = P_OFF_R + RLANES * 4;                    // 64 floats inside raw buffer 0's never-written tail
-static_assert(RLANES * 4 + DCO <= RAWF, "bias row must fit the raw buffer's slack");
-
-template <bool PS>
-__global__ void __launch_bounds__(kThreads, 2) conv3x3_winod_persist_kernel(const float* __restrict__ xg,
-                                                                            const float* __restrict__ wpk,
-                                                                            const float* __restrict__ bias,
-                                                                            const float* __restrict__ res,
-                                                                            float* __restrict__ out, WinoParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[P_LDS_FLOATS];
-    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cbk = wv & 1, tb = (wv >> 1) & 1, ih = wv >> 2;
-    const int H = p.H, W = p.W, nch = p.nchunks;
-    const long long HW = (long long)H * W;
-
-    // contiguous item range of this workgroup; workgroups that share an XCD (id % 8) get neighbouring ranges
-    const int nwg = gridDim.x, bq = nwg >> 3, br = nwg & 7, xcd = blockIdx.x & 7;
-    const int vb_ = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (blockIdx.x >> 3);
-    const int per = (p.n_blocks + nwg - 1) / nwg;
-    const int it0 = vb_ * per, it1 = min(it0 + per, p.n_blocks);
-    if (it0 >= it1) return;                                  // block-uniform
-
-    // per-thread constants of the raw-tile DMA map: L = (2 wv + i) * 64 + lane <-> (channel, row, float4 q)
-    int r_ch[RINSTR], r_row[RINSTR], r_q4[RINSTR];
-    bool r_live[RINSTR];
-#pragma unroll
-    for (int i = 0; i < RINSTR; ++i) {
-        const int L = (RINSTR * wv + i) * 64 + lane;
-        const int seg = L / RQ, q = L - seg * RQ, ch = seg / RROWS;
-        r_ch[i] = ch; r_row[i] = seg - ch * RROWS; r_q4[i] = 4 * q; r_live[i] = L < RLANES;
-    }
-    auto decode = [&](int item, int& n, int& cg, int& ty0, int& tx0) {
-        const int tile = item % p.tiles;
-        const int rest = item / p.tiles;
-        cg = rest % p.cgs;
-        n = rest / p.cgs;
-        ty0 = (tile / p.tiles_x) * (2 * TROWS);
-        tx0 = (tile % p.tiles_x) * (2 * TCOLS);
-    };
-    // DMA of chunk `c` of item `item` into buffer parity `b` (item may be one or two ahead of the item being computed)
-    auto issue_dma = [&](int item, int c, int b) {
-        int n, cg, ty0, tx0;
-        decode(item, n, cg, ty0, tx0);
-        const float* __restrict__ xc = xg + ((long long)n * p.Cin + (long long)c * DCK) * HW;
-        const int cin_left = p.Cin - c * DCK;
-        float* rb = lds + P_OFF_R + b * RAWF;
-#pragma unroll
-        for (int i = 0; i < RINSTR; ++i) {
-            const int gy = ty0 - 1 + r_row[i], gx = tx0 - 4 + r_q4[i];
-            const bool ok = r_live[i] && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W && r_ch[i] < cin_left;
-            if (ok)                                          // exec mask: lanes outside the image do not load (masked at transform)
-                __builtin_amdgcn_global_load_lds((glb_void_t*)(xc + (r_ch[i] * HW + (long long)gy * W + gx)),
-                                                 (lds_void_t*)(rb + (RINSTR * wv + i) * 256), 16, 0, 0);
-        }
-        const float* __restrict__ wc = wpk + ((long long)cg * nch + c) * DUF;
-        float* ub = lds + P_OFF_U + b * DUF;
-#pragma unroll
-        for (int i = 0; i < UINSTR; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(wc + ((UINSTR * wv + i) * 64 + lane) * 4),
-                                             (lds_void_t*)(ub + (UINSTR * wv + i) * 256), 16, 0, 0);
-    };
-    // the chunk `k` steps after (item, c) in the workgroup's global chunk stream; false past the end of the range
-    auto ahead = [&](int item, int c, int k, int& item2, int& c2) {
-        const int lin = c + k;
-        item2 = item + lin / nch;
-        c2 = lin % nch;
-        return item2 < it1;
-    };
-
-    const int st = tid & 63, cs = tid >> 6, str = st >> 5, stc = st & 31;
-    const int rbase = (cs * RROWS + 2 * str) * RCOLS + 2 * stc + 2;
-    auto transform = [&](int c, int b, unsigned pmask) {
-        const float* rb = lds + P_OFF_R + b * RAWF + rbase;
-        float* vb = lds + P_OFF_V;
-        const bool okc = c * DCK + cs < p.Cin;
-        f32x2 pr[12];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) pr[r * 3 + k] = *reinterpret_cast<const f32x2*>(rb + r * RCOLS + 2 * k);
-        float d[16], t[16];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool m0 = okc && ((pmask >> (r * 3 + 0)) & 1u), m1 = okc && ((pmask >> (r * 3 + 1)) & 1u),
-                       m2 = okc && ((pmask >> (r * 3 + 2)) & 1u);
-            d[r * 4 + 0] = m0 ? pr[r * 3 + 0].y : 0.f;
-            d[r * 4 + 1] = m1 ? pr[r * 3 + 1].x : 0.f;
-            d[r * 4 + 2] = m1 ? pr[r * 3 + 1].y : 0.f;
-            d[r * 4 + 3] = m2 ? pr[r * 3 + 2].x : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
-            t[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
-            t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
-            t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            vb[((i * 4 + 0) * DCK + cs) * NT + st] = t[i * 4 + 0] - t[i * 4 + 2];
-            vb[((i * 4 + 1) * DCK + cs) * NT + st] = t[i * 4 + 1] + t[i * 4 + 2];
-            vb[((i * 4 + 2) * DCK + cs) * NT + st] = t[i * 4 + 2] - t[i * 4 + 1];
-            vb[((i * 4 + 3) * DCK + cs) * NT + st] = t[i * 4 + 1] - t[i * 4 + 3];
-        }
-    };
-    auto patch_mask = [&](int ty0, int tx0) {
-        unsigned m = 0;
-#pragma unroll
-        for (int e = 0; e < 12; ++e) {
-            const int y = ty0 + 2 * str - 1 + e / 3, x = tx0 + 2 * stc - 2 + 2 * (e % 3);
-            if (y >= 0 && y < H && x >= 0 && x + 1 < W) m |= 1u << e;
-        }
-        return m;
-    };
-
-    const int aoff = half * DCO + cbk * 32 + l32 + (8 * ih) * DCK * DCO;
-    const int boff = half * NT + tb * 32 + l32 + (8 * ih) * DCK * NT;
-    const float* vbuf = lds + P_OFF_V;
-    f32x2* xch = reinterpret_cast<f32x2*>(lds + P_OFF_V);    // 64 KB: V + the spare 32 KB
-    float* sbias = lds + P_OFF_B;
-
-    // ---- pipeline prologue: chunks 0 and 1 of the stream
-    int n, cg, ty0, tx0;
-    decode(it0, n, cg, ty0, tx0);
-    issue_dma(it0, 0, 0);
-    sync_all();
-    {
-        int i2, c2;
-        if (ahead(it0, 0, 1, i2, c2)) issue_dma(i2, c2, 1);
-    }
-    transform(0, 0, patch_mask(ty0, tx0));
-    sync_lds();
-
-    int G = 0;                                               // global chunk counter: buffer parity = G & 1
-    for (int item = it0; item < it1; ++item) {
-        f32x16 acc[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-        const unsigned pmask = patch_mask(ty0, tx0);
-        const int ry = ty0 + 2 * tb + ih, rx0 = tx0 + 2 * l32;   // this wave finalises output row `ih` of its tiles
-        f32x2 rres[16];
-
-        for (int c = 0; c < nch; ++c, ++G) {
-            const float* ub = lds + P_OFF_U + (G & 1) * DUF;
-            if constexpr (!PS) {
-                if (c + 1 == nch && res) {                   // block-uniform: skip tensor fetched under the last MFMA phase
-                    const long long plane = HW;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int co0 = cg * DCO + cbk * 32 + 8 * g + 4 * half;
-                        const long long base = ((long long)n * p.Cout + co0) * plane + (long long)ry * W + rx0;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const bool ok = ry < H && rx0 < W && co0 + r < p.Cout;
-                            rres[4 * g + r] = *reinterpret_cast<const f32x2*>(res + (ok ? base + r * plane : 0));
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-#pragma unroll
-                for (int kp = 0; kp < DCK / 2; ++kp) {
-                    const float av = ub[aoff + (a * DCK + 2 * kp) * DCO];
-                    const float bv = vbuf[boff + (a * DCK + 2 * kp) * NT];
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
-                }
-            }
-            sync_all();                                      // this chunk is consumed everywhere; chunk G+1 has landed
-            {
-                int i2, c2;
-                if (ahead(item, c, 2, i2, c2)) issue_dma(i2, c2, G & 1);   // U / raw buffer (G & 1) is free again
-            }
-            if (c + 1 < nch) {
-                transform(c + 1, (G + 1) & 1, pmask);
-                sync_lds();
-            }
-        }
-
-        // ---- epilogue (as conv3x3_wino.hip): half column transform, exchange with the SIMD partner, bias / ReLU /
-        //      residual, stores.  V is free (last MFMA phase retired at the barrier above); U / raw hold the next item.
-        if (tid < DCO) {
-            const int co = cg * DCO + tid;
-            sbias[tid] = (bias && co < p.Cout) ? bias[co] : 0.f;
-        }
-        f32x2 keep[16];
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            float ma[2][2];
-#pragma unroll
-            for (int il = 0; il < 2; ++il) {
-                const float m0 = acc[il * 4 + 0][reg], m1 = acc[il * 4 + 1][reg], m2 = acc[il * 4 + 2][reg], m3 = acc[il * 4 + 3][reg];
-                ma[il][0] = m0 + m1 + m2;
-                ma[il][1] = m1 - m2 - m3;
-            }
-            f32x2 send;
-            if (ih == 0) {
-                keep[reg] = f32x2{ma[0][0] + ma[1][0], ma[0][1] + ma[1][1]};
-                send = f32x2{ma[1][0], ma[1][1]};
-            } else {
-                keep[reg] = f32x2{-ma[0][0] - ma[1][0], -ma[0][1] - ma[1][1]};
-                send = f32x2{ma[0][0], ma[0][1]};
-            }
-            xch[(wv * 16 + reg) * 64 + lane] = send;
-        }
-        sync_lds();
-        const bool pok2 = ry < H && rx0 < W;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co0 = cg * DCO + cbk * 32 + 8 * g + 4 * half;
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + cbk * 32 + 8 * g + 4 * half);
-            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-            f32x2 Y[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const f32x2 o = xch[((wv ^ 4) * 16 + 4 * g + r) * 64 + lane];
-                Y[r] = f32x2{keep[4 * g + r].x + o.x + bb[r], keep[4 * g + r].y + o.y + bb[r]};
-                if (p.relu) Y[r] = f32x2{fmaxf(Y[r].x, 0.f), fmaxf(Y[r].y, 0.f)};
-            }
-            if constexpr (PS) {
-                if (pok2 && co0 < p.Cout) {
-                    const long long W2 = 2ll * W;
-                    float* o = out + (((long long)n * (p.Cout >> 2) + (co0 >> 2)) * (2ll * H) + 2 * ry) * W2 + 2 * rx0;
-                    *reinterpret_cast<f32x4*>(o) = f32x4{Y[0].x, Y[1].x, Y[0].y, Y[1].y};
-                    *reinterpret_cast<f32x4*>(o + W2) = f32x4{Y[2].x, Y[3].x, Y[2].y, Y[3].y};
-                }
-            } else {
-                const long long base = ((long long)n * p.Cout + co0) * HW + (long long)ry * W + rx0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = pok2 && co0 + r < p.Cout;
-                    f32x2 v = Y[r];
-                    if (res) v = f32x2{v.x + rres[4 * g + r].x, v.y + rres[4 * g + r].y};   // block-uniform
-                    if (ok) *reinterpret_cast<f32x2*>(out + base + r * HW) = v;
-                }
-            }
-        }
-        // ---- hand over to the next item: its chunk 0 landed before the last barrier of the chunk loop
-        if (item + 1 < it1) {
-            decode(item + 1, n, cg, ty0, tx0);
-            sync_lds();                                      // every wave has read its exchange values: V may be rewritten
-            transform(0, G & 1, patch_mask(ty0, tx0));
-            sync_lds();
-        }
-    }
-}
 
 }  // namespace
 }  // namespace kmsr
@@ -639,24 +373,10 @@ extern "C" int kmsr_conv3x3_winod_fwd_f32(const kmsr_conv3x3_desc* d, const floa
     if (nblocks > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv grid too large");
     p.n_blocks = (int)nblocks;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static const int persist = [] { const char* e = getenv("KMSR_WINOD_PERSIST"); return e ? atoi(e) : 0; }();   // measured: the one-tile kernel with 3-deep raw prefetch is faster (437 vs 462 us)
-    if (persist) {
-        // persistent form: one workgroup per CU walks ceil(items / grid) consecutive items
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            int v = 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-        }
-        const int grid = (int)std::min<long long>(nblocks, cus);
-        if (d->pixel_shuffle)
-            conv3x3_winod_persist_kernel<true><<<grid, kThreads, 0, stream>>>(x, packed_w, bias, residual, out, p);
-        else
-            conv3x3_winod_persist_kernel<false><<<grid, kThreads, 0, stream>>>(x, packed_w, bias, residual, out, p);
-    } else if (d->pixel_shuffle) {
+    if (d->pixel_shuffle)
         conv3x3_winod_kernel<true><<<p.n_blocks, kThreads, 0, stream>>>(x, packed_w, bias, residual, out, p);
-    } else {
+    else
         conv3x3_winod_kernel<false><<<p.n_blocks, kThreads, 0, stream>>>(x, packed_w, bias, residual, out, p);
-    }
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
 }

@@ -17,9 +17,6 @@
 //     arrive through the scalar cache (wave-uniform), no block-level barriers exist.
 //   - degrade_generic_kernel: one thread per output, any F / kernel size / alignment.
 #include "kmsr_common.h"
-#ifndef KMSR_ABLATE
-#define KMSR_ABLATE 0
-#endif
 #ifndef KMSR_DMA_AUX
 #define KMSR_DMA_AUX 0  // cache policy of the HR row stream (2 = nt)
 #endif
@@ -27,7 +24,6 @@
 #include "kmsr_noise.h"
 
 #include <algorithm>
-#include <cstdlib>
 
 namespace kmsr {
 
@@ -304,11 +300,9 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
 #pragma unroll
         for (int t = 0; t < NLD; ++t) {
             if (live[t]) {                                      // wave-uniform: exactly one VMEM instruction
-#if KMSR_ABLATE != 2
                 if (inside[t])                                  // exec mask; LDS dest = slot + 256 t + 4 lane
                     __builtin_amdgcn_global_load_lds((glb_void_t*)(rp + 4 * (lane + kWave * t)),
                                                      (lds_void_t*)(slot + 4 * kWave * t), 16, 0, KMSR_DMA_AUX);
-#endif
             }
         }
     };
@@ -365,21 +359,9 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
                     const float* __restrict__ tp = taps + (up ? TY - 1 - al : al) * TXP;
 #pragma unroll
                     for (int b = 0; b < TX; ++b) {
-#if KMSR_ABLATE == 3
-                        const float kv = 0.01f * (float)(b + 1);
-#else
                         const float kv = tp[b];
-#endif
-#if KMSR_ABLATE == 1
-                        if (b == 0)
-#pragma unroll
-                            for (int x = 0; x < NX; ++x) acc[m][x] += kv;
-#pragma unroll
-                        for (int x = 0; x < NX; ++x) asm volatile("" ::"v"(win[x][OFF + b]));
-#else
 #pragma unroll
                         for (int x = 0; x < NX; ++x) acc[m][x] = fmaf(kv, win[x][OFF + b], acc[m][x]);
-#endif
                     }
                 }
             }
@@ -598,10 +580,7 @@ extern "C" int kmsr_degrade_f32(const kmsr_degrade_desc* d, const float* hr, con
         return KMSR_OK;
     }
 
-    int NX = NX_auto;
-    int ring = kRing;
-    if (const char* e = getenv("KMSR_DEGRADE_NX")) NX = atoi(e) == 1 ? 1 : 2;      // tuning overrides
-    if (const char* e = getenv("KMSR_DEGRADE_RING")) ring = atoi(e);
+    const int NX = NX_auto;
     const int SW = kWave * NX;
     p.n_strips = ceil_div(g.w, SW);
     p.n_chunks = ceil_div(g.h, rows);
@@ -614,15 +593,8 @@ extern "C" int kmsr_degrade_f32(const kmsr_degrade_desc* d, const float* hr, con
     degrade_rowstream_kernel<F_, TY_, TX_, PH_, PW_, NX_, R_><<<grid, block, 0, stream>>>(hr, p.taps, sigma, noise, lr, p)
 #define X(F_, TY_, TX_, PH_, PW_)                                                      \
     if (g.F == F_ && g.TY == TY_ && g.TX == TX_ && g.ph == PH_ && g.pw == PW_) {       \
-        if (NX == 2) {                                                                 \
-            if (ring == 3) KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 2, 3);                  \
-            else if (ring == 6) KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 2, 6);             \
-            else KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 2, 4);                            \
-        } else {                                                                       \
-            if (ring == 3) KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 1, 3);                  \
-            else if (ring == 6) KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 1, 6);             \
-            else KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 1, 4);                            \
-        }                                                                              \
+        if (NX == 2) KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 2, kRing);                    \
+        else KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 1, kRing);                            \
     } else
     KMSR_ROWSTREAM_TABLE(X) { return fail(KMSR_E_UNSUPPORTED, "internal: no instantiation"); }
 #undef X

@@ -47,10 +47,34 @@ def _as_dev_f32(t, dev):
     return t.to(device=dev, dtype=torch.float32)
 
 
+_CHECKED_IDX = {}     # (data_ptr, version, numel, bound) of device index tensors already range-checked
+
+
+def _checked_index(idx, n, bound, what, device, dtype):
+    """Index tensors are range-checked on the host (the reference's np.random.randint / einsum gather cannot leave
+    [0, bound); an out-of-range index here would be an out-of-bounds DEVICE read of taps, sigma or the noise pool).
+    CPU tensors are checked before the copy (no device sync); a device tensor costs one min/max read-back the first time
+    it is seen and nothing on later calls with the same unmodified tensor (the steady state of a training loop)."""
+    if idx.numel() != n:
+        raise AssertionError(f"{what} must hold one index per sample ({n}), got {idx.numel()}")
+    if idx.device.type != "cuda":
+        if n and (int(idx.min()) < 0 or int(idx.max()) >= bound):
+            raise IndexError(f"{what} out of range [0, {bound}): min {int(idx.min())}, max {int(idx.max())}")
+        return idx.to(device=device, dtype=dtype).contiguous()
+    key = (idx.data_ptr(), idx._version, n, bound)
+    if _CHECKED_IDX.get(what) != key:
+        if n:
+            lo, hi = (int(v) for v in torch.aminmax(idx))
+            if lo < 0 or hi >= bound:
+                raise IndexError(f"{what} out of range [0, {bound}): min {lo}, max {hi}")
+        _CHECKED_IDX[what] = key
+    return idx.to(device=device, dtype=dtype).contiguous()
+
+
 def degrade_batch(hr, kernels, factor, *, down="avgpool", pad="replicate", normalize=True,
                   kernel_idx=None, sigma=None, noise="none", seed=0, offset=0,
                   noise_pool=None, noise_idx=None, out=None, flags=0, rows_per_chunk=0, workspace=None,
-                  taps_ready=False):
+                  taps_ready=False, validate_idx=True):
     """One fused blur + downsample + noise launch over a batch.
 
     hr       [N,C,H,W] float32 CUDA tensor (any N/C/H strides, unit W stride)
@@ -60,6 +84,8 @@ def degrade_batch(hr, kernels, factor, *, down="avgpool", pad="replicate", norma
     noise    "none" | "gaussian" (sigma [K,C], train_gemini.py:137-138) | "pool" (noise_pool [P,C,h,w], E:72-74)
     workspace / taps_ready: pass the same float32 CUDA tensor to successive calls that use the SAME kernels and
              geometry and set taps_ready=True from the second call on to skip rebuilding the tap table.
+    validate_idx: range-check kernel_idx / noise_idx on the host (IndexError); pass False only for indices that are in
+             range by construction (an argmax over K logits), to keep the call free of a device read-back.
     Returns lr [N,C,h,w] float32 on the same device.
     """
     dev = L.require_gpu()
@@ -89,8 +115,11 @@ def degrade_batch(hr, kernels, factor, *, down="avgpool", pad="replicate", norma
     L.check(lib.kmsr_degrade_out_shape(d, h, w))
     h, w = h.value, w.value
     if kernel_idx is not None:
-        kernel_idx = kernel_idx.to(device=hr.device, dtype=torch.int32).contiguous()
-        assert kernel_idx.numel() == N
+        if validate_idx:
+            kernel_idx = _checked_index(kernel_idx, N, kernels.shape[0], "kernel_idx", hr.device, torch.int32)
+        else:
+            kernel_idx = kernel_idx.to(device=hr.device, dtype=torch.int32).contiguous()
+            assert kernel_idx.numel() == N
     if d.noise_mode == L.NOISE_GAUSSIAN:
         sigma = sigma.to(device=hr.device, dtype=torch.float32).contiguous()
         assert sigma.shape == (kernels.shape[0], Cc), f"sigma must be [K,C], got {tuple(sigma.shape)}"
@@ -102,8 +131,11 @@ def degrade_batch(hr, kernels, factor, *, down="avgpool", pad="replicate", norma
             f"noise pool entries {tuple(noise_pool.shape[1:])} != LR shape {(Cc, h, w)}"          # E:239-247 guard
         d.pool_size = noise_pool.shape[0]
         if noise_idx is not None:
-            noise_idx = noise_idx.to(device=hr.device, dtype=torch.int64).contiguous()
-            assert noise_idx.numel() == N
+            if validate_idx:
+                noise_idx = _checked_index(noise_idx, N, noise_pool.shape[0], "noise_idx", hr.device, torch.int64)
+            else:
+                noise_idx = noise_idx.to(device=hr.device, dtype=torch.int64).contiguous()
+                assert noise_idx.numel() == N
     else:
         noise_pool, noise_idx = None, None
     if out is None:

@@ -35,6 +35,17 @@ def shard_indices(n, rank, world):
     return list(range(rank, n, world))
 
 
+def rank_seed(base_seed, rank=None):
+    """Seed of THIS rank's counter-based noise stream.  The in-kernel Gaussian noise is addressed by (seed, offset, local
+    plane, row, col); with one seed for all ranks sample n of every rank would receive a bit-identical eps field each step,
+    unlike the reference's independent torch.randn_like draws (train_gemini.py:137).  Rank r therefore keys its stream with
+    base_seed + r * 0x9E3779B97F4A7C15 (mod 2^64, odd multiplier -> distinct keys for distinct ranks); rank 0 (and a
+    single process) keeps base_seed, so single-GPU results do not depend on whether a process group exists."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    return (int(base_seed) + int(rank) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

@@ -69,11 +69,13 @@ def process_landsat_folder(input_dir, kernel_path, output_dir, downscale_factor=
     return ok, bad
 
 
-def process_files(hr_dir, blurred_dir, noise_pool_path, output_dir, seed=42, hr_shape=(5, 256, 256), lr_shape=(5, 32, 32)):
+def process_files(hr_dir, blurred_dir, noise_pool_path, output_dir, seed=42, hr_shape=(5, 256, 256), lr_shape=(5, 32, 32),
+                  batch_size=256):
     """E_make_train_data.py:187-272 on .npy: for every name present in both folders, lr = blurred + noise_pool[idx] with
     idx drawn per file from the global NumPy RNG seeded like E:190, in sorted file order; writes output_dir/<name>_train.npz
     with arrays `hr` and `lr` (the reference writes the same two groups to NetCDF, E:77-117).  Files whose shapes fail the
-    guards (E:239-247) are skipped.  Returns (n_success, n_skipped)."""
+    guards (E:239-247) are skipped.  At most `batch_size` files are held in host memory at a time (one fused launch per
+    batch; the RNG stream is the same as one draw per file in file order whatever the batch size).  Returns (n_success, n_skipped)."""
     L.require_gpu()
     np.random.seed(seed)                                                     # E:190
     if not os.path.isdir(hr_dir) or not os.path.isdir(blurred_dir):
@@ -85,7 +87,19 @@ def process_files(hr_dir, blurred_dir, noise_pool_path, output_dir, seed=42, hr_
     if not names:
         raise FileNotFoundError(f"no .npy files in {blurred_dir}")                       # E:210
     os.makedirs(output_dir, exist_ok=True)
-    good, skipped = [], 0
+    done = skipped = 0
+    pending = []
+
+    def flush():
+        nonlocal done, pending
+        if pending:
+            # one draw per surviving file, in file order, exactly like sequential add_noise calls (E:250 -> E:72)
+            lr = add_noise_batch(np.stack([b for _, _, b in pending]), pool)
+            for (f, hr, _), l in zip(pending, lr):
+                np.savez(os.path.join(output_dir, os.path.splitext(f)[0] + "_train.npz"), hr=hr, lr=l)
+            done += len(pending)
+            pending = []
+
     for f in names:
         try:
             hr = np.load(os.path.join(hr_dir, f)).astype(np.float32)
@@ -94,14 +108,12 @@ def process_files(hr_dir, blurred_dir, noise_pool_path, output_dir, seed=42, hr_
                 print(f"skip {f}: HR {hr.shape} / blurred {bl.shape}")
                 skipped += 1
                 continue
-            good.append((f, hr, bl))
+            pending.append((f, hr, bl))
+            if len(pending) >= batch_size:
+                flush()
         except Exception as e:  # noqa: BLE001  (E:264-267)
             print(f"failed on {f}: {e}")
             skipped += 1
-    if good:
-        # one draw per surviving file, in file order, exactly like sequential add_noise calls (E:250 -> E:72)
-        lr = add_noise_batch(np.stack([b for _, _, b in good]), pool)
-        for (f, hr, _), l in zip(good, lr):
-            np.savez(os.path.join(output_dir, os.path.splitext(f)[0] + "_train.npz"), hr=hr, lr=l)
-    print(f"done: {len(good)} ok, {skipped} skipped")
-    return len(good), skipped
+    flush()
+    print(f"done: {done} ok, {skipped} skipped")
+    return done, skipped

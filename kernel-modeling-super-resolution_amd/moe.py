@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib as L
+from . import dist as kd
 from .degradation import DegradeFunction, degrade_batch
 from .sr import Conv3x3Function, conv3x3, pack_conv3x3_weight
 
@@ -96,7 +97,8 @@ class ContentAdaptiveDegradation(nn.Module):
         initial_kernels += torch.randn_like(initial_kernels) * 0.01
         self.kernel_bank = nn.Parameter(initial_kernels)                  # :62
         self.sigma_bank = nn.Parameter(torch.ones(n_kernels, n_channels) * 0.5)   # :66
-        self.noise_seed = 0       # (seed, offset) of the counter-based noise stream; offset advances per forward
+        self.noise_seed = 0       # (seed, offset) of the counter-based noise stream; offset advances per forward; the key
+        #                           actually used is dist.rank_seed(noise_seed): every data-parallel rank draws its own eps field
         self.noise_offset = 0
         self.downscale = 4        # train_gemini.py:134  out[:, :, ::4, ::4]
 
@@ -127,8 +129,8 @@ class ContentAdaptiveDegradation(nn.Module):
         valid_sigmas = self.get_effective_sigmas()                                  # :108
         batch_kernels = torch.einsum('bk, kchw -> bchw', weights, valid_kernels)    # :112
         batch_sigmas = torch.einsum('bk, kc -> bc', weights, valid_sigmas)          # :115
-        out = DegradeFunction.apply(x.detach(), batch_kernels, batch_sigmas, self.downscale, "zero", self.noise_seed,
-                                    self.noise_offset)
+        out = DegradeFunction.apply(x.detach(), batch_kernels, batch_sigmas, self.downscale, "zero",
+                                    kd.rank_seed(self.noise_seed), self.noise_offset)
         self.noise_offset += 1
         return out, weights, valid_kernels
 
@@ -144,12 +146,14 @@ class ContentAdaptiveDegradation(nn.Module):
             # hard selection: einsum('bk,kchw->bchw') with one-hot weights IS a gather (:112-115)
             out = degrade_batch(x, valid_kernels, self.downscale, down="stride", pad="zero", normalize=False,
                                 kernel_idx=weights.argmax(dim=1).to(torch.int32), sigma=valid_sigmas, noise="gaussian",
-                                seed=self.noise_seed, offset=self.noise_offset)
+                                seed=kd.rank_seed(self.noise_seed), offset=self.noise_offset,
+                                validate_idx=False)        # an argmax over the K logits is in [0, K) by construction
         else:
             batch_kernels = torch.einsum('bk, kchw -> bchw', weights, valid_kernels)   # :112
             batch_sigmas = torch.einsum('bk, kc -> bc', weights, valid_sigmas)        # :115
             out = degrade_batch(x, batch_kernels, self.downscale, down="stride", pad="zero", normalize=False,
-                                sigma=batch_sigmas, noise="gaussian", seed=self.noise_seed, offset=self.noise_offset)
+                                sigma=batch_sigmas, noise="gaussian", seed=kd.rank_seed(self.noise_seed),
+                                offset=self.noise_offset)
         self.noise_offset += 1
         return out, weights, valid_kernels
 
@@ -171,6 +175,6 @@ class NoiseEstimator(nn.Module):
         one = torch.ones((1, x.shape[1], 1, 1), device=x.device)
         # identity blur (1x1 kernel, stride 1) + Gaussian epilogue of the fused kernel
         out = degrade_batch(x, one, 1, down="stride", pad="zero", normalize=False, sigma=sigma.view(1, -1),
-                            noise="gaussian", seed=self.noise_seed, offset=self.noise_offset)
+                            noise="gaussian", seed=kd.rank_seed(self.noise_seed), offset=self.noise_offset)
         self.noise_offset += 1
         return out, sigma

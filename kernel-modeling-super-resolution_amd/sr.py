@@ -154,6 +154,10 @@ class Conv3x3Function(torch.autograd.Function):
     def forward(ctx, x, weight, bias, relu, residual=None, pixel_shuffle=False):
         """residual (same shape as the conv output) is added and PixelShuffle(2) applied in the kernel's epilogue, so the
         training graph has no separate add / permutation passes in the forward direction."""
+        if residual is not None and (relu or pixel_shuffle):
+            # the epilogue is relu(conv + b) + residual (kmsr.h): the ReLU mask could not be taken from the saved output, and
+            # the ABI rejects residual + pixel_shuffle; no layer of the SR / selector nets needs either combination
+            raise ValueError("Conv3x3Function: residual cannot be combined with relu or pixel_shuffle")
         x = x.contiguous()
         y = Conv3x3Function._run(x, weight.detach(), bias, relu, residual, pixel_shuffle)
         ctx.relu = relu

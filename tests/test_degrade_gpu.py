@@ -102,6 +102,18 @@ def test_va_error_behaviour(gpu_device):
     idx = torch.zeros(2, dtype=torch.int32).cuda()
     rc = lib.kmsr_degrade_f32(d, L.ptr(hr), L.ptr(ker), L.ptr(idx), None, None, None, L.ptr(lr), L.ptr(ws), 64, None)
     assert rc == L.KMSR_E_NOMEM and b"workspace" in lib.kmsr_last_error()
+    # kernel / noise-pool indices outside their bank: IndexError on the host, never a device read out of bounds
+    hr5 = torch.rand(2, 5, 64, 64).cuda()
+    bank = torch.rand(3, 5, 13, 13).cuda()
+    for bad in (torch.tensor([0, 3]), torch.tensor([-1, 1]), torch.tensor([0, 3]).cuda()):
+        with pytest.raises(IndexError):
+            kmsr_amd.degrade_batch(hr5, bank, 4, down="stride", pad="zero", normalize=False, kernel_idx=bad)
+    pool = torch.rand(4, 5, 16, 16).cuda()
+    with pytest.raises(IndexError):
+        kmsr_amd.degrade_batch(hr5, bank[:1], 4, down="stride", pad="zero", normalize=False, noise="pool", noise_pool=pool,
+                               noise_idx=torch.tensor([1, 4]))
+    ok = kmsr_amd.degrade_batch(hr5, bank, 4, down="stride", pad="zero", normalize=False, kernel_idx=torch.tensor([2, 0]).cuda())
+    assert tuple(ok.shape) == (2, 5, 16, 16)
 
 
 @pytest.mark.parametrize("name,fast", [("b4_256", True), ("b3_250x253", False), ("b2_64", True)])

@@ -62,5 +62,11 @@ def test_process_files(tmp_path, gpu_device):
         z = np.load(outd / (n[:-4] + "_train.npz"))
         assert np.array_equal(z["hr"], data[n][0])
         assert np.array_equal(z["lr"], data[n][1] + pool[idx])
+    # bounded host buffering: batches of 3 files give byte-identical outputs (same RNG stream, one draw per file in order)
+    out2 = tmp_path / "train_b3"
+    assert kmsr_amd.process_files(str(hrd), str(bld), str(tmp_path / "pool.npy"), str(out2), seed=42, batch_size=3) == (4, 1)
+    for n in names:
+        a, b = np.load(outd / (n[:-4] + "_train.npz")), np.load(out2 / (n[:-4] + "_train.npz"))
+        assert np.array_equal(a["lr"], b["lr"]) and np.array_equal(a["hr"], b["hr"])
     with pytest.raises(FileNotFoundError):
         kmsr_amd.process_files(str(hrd), str(bld), str(tmp_path / "nope.npy"), str(outd))

@@ -257,3 +257,22 @@ def test_patch_discriminator_matches_reference():
     assert_close(D.net[0].weight_u.numpy(), MB["D_train_u0"], rtol=1e-5, atol=1e-6, what="spectral-norm u after one step")
     assert_close(D.net[0].weight_orig.grad.numpy(), MB["D_train_d_w0"], rtol=1e-3,
                  atol=1e-4 * np.abs(MB["D_train_d_w0"]).max(), what="d weight_orig")
+
+
+# ------------------------------------------------------------------ stock-torch form of the degradation (bench.py's second CPU baseline)
+@pytest.mark.parametrize("name", VA_NAMES)
+def test_va_torch_ops_form(name):
+    """oracle/torch_ops.va_torch (F.pad -> F.conv2d -> F.avg_pool2d, C_30:107-122) against the same reference fixtures."""
+    from oracle.torch_ops import va_torch
+    C, H, W, f, seed = VA[name + "__meta"]
+    out = va_torch(landsat_like((C, H, W), int(seed)), VA[name + "__kernel"], int(f)).numpy()
+    assert_close(out, VA[name + "__out"], rtol=2e-6, what=name)
+
+
+@pytest.mark.parametrize("name", ["b4_256", "b3_250x253", "b2_64"])
+def test_vb_torch_ops_form(name):
+    """oracle/torch_ops.vb_torch (grouped F.conv2d, padding 6, then [::4, ::4]; train_gemini.py:124-134)."""
+    from oracle.torch_ops import vb_torch
+    B, C, H, W, seed = VB[name + "__meta"]
+    out = vb_torch(landsat_like((B, C, H, W), int(seed)), K["moe_kernels"][VB[name + "__kid"]], 4).numpy()
+    assert_close(out, VB[name + "__out"], rtol=2e-6, what=name)

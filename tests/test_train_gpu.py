@@ -57,6 +57,21 @@ def test_autograd_function_matches_torch(gpu_device):
         assert _rel(yc, yr) < 1e-5 and _rel(xc.grad, xr.grad) < 2e-5 and _rel(wc.grad, wr.grad) < 2e-5 and _rel(bc.grad, br.grad) < 2e-5
 
 
+def test_autograd_function_rejects_unsupported_epilogues(gpu_device):
+    """relu + residual (mask not recoverable from the saved output) and residual + pixel_shuffle are refused, not silently wrong."""
+    x = torch.randn(1, 16, 8, 8, device="cuda", requires_grad=True)
+    w = torch.randn(16, 16, 3, 3, device="cuda", requires_grad=True)
+    r = torch.randn(1, 16, 8, 8, device="cuda", requires_grad=True)
+    with pytest.raises(ValueError):
+        Conv3x3Function.apply(x, w, None, True, r)
+    with pytest.raises(ValueError):
+        Conv3x3Function.apply(x, w, None, False, torch.randn(1, 4, 16, 16, device="cuda"), True)
+    # residual alone: d/d residual is the incoming gradient
+    y = Conv3x3Function.apply(x, w, None, False, r)
+    y.sum().backward()
+    assert torch.equal(r.grad, torch.ones_like(r))
+
+
 def test_srnet_training_step_matches_oracle(gpu_device):
     """One Adam step on identical weights / data: loss, every gradient and the updated weights agree with the
     stock-torch oracle on the CPU."""
