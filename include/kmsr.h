@@ -228,6 +228,17 @@ int kmsr_conv3x3_winod_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int
 int kmsr_conv3x3_winod_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
                                const float* residual, float* out, void* stream);
 
+/* "V in registers" form of the LDS-DMA Winograd kernel: same math, epilogues, tolerances and preconditions (W % 4 == 0,
+ * 16-byte aligned x / packed_w).  The workgroup's 8 waves are (transform row i) x (tile row): each lane computes the MFMA
+ * B operand (its tiles' transformed inputs for row i) itself from the raw input rows in LDS, inside the previous chunk's
+ * MFMA phase, so the transformed inputs never go through LDS and a chunk costs ONE barrier instead of two.
+ * Packed layout [ceil(Cout/64)][ceil(Cin/8)][4 rows][8 (cout block, channel pair)][64 lanes][4 columns]. */
+size_t kmsr_conv3x3_winov_packed_weight_floats(int32_t Cin, int32_t Cout);
+int kmsr_conv3x3_winov_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int32_t Cin, int32_t Cout, float* packed,
+                                        void* stream);
+int kmsr_conv3x3_winov_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
+                               const float* residual, float* out, void* stream);
+
 /* ============================================================================================
  * 5x5 convolution (zero padding 2) with PixelShuffle(4) fused into the store -- the COLLAPSED SR upsampler.
  * up1 (3x3 F->4F) -> PixelShuffle(2) -> up2 (3x3 F->4F) -> PixelShuffle(2) -> tail (3x3 F->bands) contains no

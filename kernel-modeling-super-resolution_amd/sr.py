@@ -57,6 +57,18 @@ def pack_conv3x3_weight_wino_dma(weight):
     return packed
 
 
+def pack_conv3x3_weight_wino_vreg(weight):
+    """[Cout,Cin,3,3] -> G g G^T packed for conv3x3(..., algo="winograd_vreg") (a lane's four transform columns adjacent)."""
+    lib = L.load()
+    assert weight.is_cuda and weight.dtype == torch.float32 and weight.ndim == 4 and weight.shape[2:] == (3, 3)
+    w = weight.detach().contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    packed = torch.empty(lib.kmsr_conv3x3_winov_packed_weight_floats(Cin, Cout), device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        L.check(lib.kmsr_conv3x3_winov_pack_weights_f32(L.ptr(w), Cin, Cout, L.ptr(packed), L.current_stream()))
+    return packed
+
+
 def winograd_eligible(cin, cout, stride=1, width=2):
     """Where the Winograd kernel applies/pays: stride 1, even width (patch rows are fetched as aligned float2) and
     enough channels that the 64x16 chunk tiles are not mostly padding."""
@@ -73,7 +85,7 @@ def pick_algo(cin, cout, stride, width, use_winograd=True):
 
 def pack_for(algo, weight):
     return {"direct": pack_conv3x3_weight, "winograd": pack_conv3x3_weight_wino,
-            "winograd_dma": pack_conv3x3_weight_wino_dma}[algo](weight)
+            "winograd_dma": pack_conv3x3_weight_wino_dma, "winograd_vreg": pack_conv3x3_weight_wino_vreg}[algo](weight)
 
 
 def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuffle=False, stride=1, out=None,
@@ -85,18 +97,19 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     if not (x.is_cuda and x.dtype == torch.float32 and x.ndim == 4):
         raise ValueError("x must be a 4-D float32 CUDA tensor")
     x = x.contiguous()
-    if algo == "winograd_dma" and x.data_ptr() % 16:
+    if algo in ("winograd_dma", "winograd_vreg") and x.data_ptr() % 16:
         x = x.clone()                    # a view at an odd storage offset: the LDS-DMA kernel fetches 16-byte pieces
     N, Cin, H, W = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     d = L.Conv3x3Desc()
     d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, Cin, H, W, int(cout), int(stride)
     d.relu, d.pixel_shuffle = int(bool(relu)), int(bool(pixel_shuffle))
-    wino = algo in ("winograd", "winograd_dma")
+    wino = algo in ("winograd", "winograd_dma", "winograd_vreg")
     if wino and stride != 1:
         raise NotImplementedError("winograd conv needs stride 1")
     need = {"direct": lib.kmsr_conv3x3_packed_weight_floats, "winograd": lib.kmsr_conv3x3_wino_packed_weight_floats,
-            "winograd_dma": lib.kmsr_conv3x3_winod_packed_weight_floats}[algo](Cin, int(cout))
+            "winograd_dma": lib.kmsr_conv3x3_winod_packed_weight_floats,
+            "winograd_vreg": lib.kmsr_conv3x3_winov_packed_weight_floats}[algo](Cin, int(cout))
     assert packed_w.is_cuda and packed_w.dtype == torch.float32 and packed_w.numel() == need, \
         f"packed weight has {packed_w.numel()} floats, conv {Cin}->{cout} needs {need}"
     oshape = (N, cout // 4, 2 * Ho, 2 * Wo) if pixel_shuffle else (N, cout, Ho, Wo)
@@ -112,7 +125,7 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
         assert tuple(residual.shape) == oshape and residual.is_cuda
     with torch.cuda.device(x.device):
         fwd = {"direct": lib.kmsr_conv3x3_fwd_f32, "winograd": lib.kmsr_conv3x3_wino_fwd_f32,
-               "winograd_dma": lib.kmsr_conv3x3_winod_fwd_f32}[algo]
+               "winograd_dma": lib.kmsr_conv3x3_winod_fwd_f32, "winograd_vreg": lib.kmsr_conv3x3_winov_fwd_f32}[algo]
         L.check(fwd(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out), L.current_stream()))
     return out
 

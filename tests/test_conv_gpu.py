@@ -111,22 +111,23 @@ WINOD_CASES = [
 ]
 
 
+@pytest.mark.parametrize("algo", ["winograd_dma", "winograd_vreg"])
 @pytest.mark.parametrize("N,Cin,H,W,Cout,bias,relu,res,ps", WINOD_CASES)
-def test_conv3x3_winograd_dma_vs_torch(N, Cin, H, W, Cout, bias, relu, res, ps, gpu_device):
-    """LDS-DMA Winograd variant: same semantics and tolerance as the register-staged Winograd kernel."""
-    from kmsr_amd.sr import pack_conv3x3_weight_wino_dma
+def test_conv3x3_winograd_dma_vs_torch(N, Cin, H, W, Cout, bias, relu, res, ps, algo, gpu_device):
+    """LDS-DMA Winograd kernels (V through LDS / V in registers): same semantics and tolerance as the register-staged one."""
+    from kmsr_amd.sr import pack_for
     g = torch.Generator().manual_seed(11 * N + Cin + Cout)
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
     b = torch.randn(Cout, generator=g) if bias else None
     oshape = (N, Cout // 4, 2 * H, 2 * W) if ps else (N, Cout, H, W)
     r = torch.randn(*oshape, generator=g) if res else None
-    out = conv3x3(x.cuda(), pack_conv3x3_weight_wino_dma(w.cuda()), Cout, bias=None if b is None else b.cuda(), relu=relu,
-                  residual=None if r is None else r.cuda(), pixel_shuffle=ps, algo="winograd_dma")
+    out = conv3x3(x.cuda(), pack_for(algo, w.cuda()), Cout, bias=None if b is None else b.cuda(), relu=relu,
+                  residual=None if r is None else r.cuda(), pixel_shuffle=ps, algo=algo)
     assert tuple(out.shape) == oshape
-    _check(out, _ref_conv(x, w, b, relu, r, ps), tol=2e-5, what=f"winograd_dma {Cin}->{Cout} {H}x{W}")
+    _check(out, _ref_conv(x, w, b, relu, r, ps), tol=2e-5, what=f"{algo} {Cin}->{Cout} {H}x{W}")
     with pytest.raises(NotImplementedError):            # W % 4 != 0 is served by the register-staged kernel
-        conv3x3(torch.zeros(1, Cin, 4, 6, device=gpu_device), pack_conv3x3_weight_wino_dma(w.cuda()), Cout, algo="winograd_dma")
+        conv3x3(torch.zeros(1, Cin, 4, 6, device=gpu_device), pack_for(algo, w.cuda()), Cout, algo=algo)
 
 
 def test_conv3x3_tap_orientation_and_channel_map(gpu_device):

@@ -264,7 +264,9 @@ def test_config4_bf16_fullsize_tile(gpu_device):
         conv = F.conv2d(F.pad(xin, pad), bf(w).cpu(), b.cpu())
         refw = bf(bf(conv) + bf(xs[:, :, wy:wy + 64, wx:wx + 64]).cpu())
         err = (outc[:, :, wy:wy + 64, wx:wx + 64].cpu() - refw).abs()
-        ulp = refw.abs().clamp_min(1e-3) * 2.0 ** -7
+        # one bf16 ulp of the CONV result (it is rounded to bf16 before the skip is added: a last-bit difference there
+        # survives the add unchanged even when conv + skip cancels to a much smaller number) or of the final value
+        ulp = torch.maximum(refw.abs(), bf(conv).abs()).clamp_min(1e-3) * 2.0 ** -7
         assert bool((err <= ulp).all()), f"bf16 body layer window {(wy, wx)}: max err {float(err.max()):.4g}"
         assert float((err == 0).float().mean()) > 0.97
 
