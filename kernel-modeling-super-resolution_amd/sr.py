@@ -104,6 +104,7 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     d = L.Conv3x3Desc()
     d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, Cin, H, W, int(cout), int(stride)
     d.relu, d.pixel_shuffle = int(bool(relu)), int(bool(pixel_shuffle))
+    d.flags = int(__import__("os").environ.get("KMSR_EXP_FLAGS", "0"), 0)
     wino = algo in ("winograd", "winograd_dma", "winograd_vreg")
     if wino and stride != 1:
         raise NotImplementedError("winograd conv needs stride 1")
@@ -123,6 +124,8 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     if residual is not None:
         residual = residual.contiguous()
         assert tuple(residual.shape) == oshape and residual.is_cuda
+        if algo == "winograd_vreg" and residual.data_ptr() % 16:
+            residual = residual.clone()  # the skip tensor is staged by 16-byte LDS-DMA pieces as well
     with torch.cuda.device(x.device):
         fwd = {"direct": lib.kmsr_conv3x3_fwd_f32, "winograd": lib.kmsr_conv3x3_wino_fwd_f32,
                "winograd_dma": lib.kmsr_conv3x3_winod_fwd_f32, "winograd_vreg": lib.kmsr_conv3x3_winov_fwd_f32}[algo]
