@@ -1,29 +1,29 @@
 // Winograd F(2x2,3x3) forward convolution on the fp32 matrix cores, "V in registers" form (semantics: include/kmsr.h;
 // same math, epilogue and tolerances as conv3x3_wino.hip / conv3x3_wino_dma.hip).
 //
-// The LDS-DMA kernel (conv3x3_wino_dma.hip) owns a CU with one 8-wave workgroup and spends ~0.7 us of every 2.4 us chunk
-// between two workgroup barriers writing the transformed inputs V to LDS while the matrix pipe idles; prologue and epilogue
-// are exposed as well (profiles/r01_wino_dma_experiments.log: pipe busy 51 %).  This kernel is built so that TWO independent
-// workgroups share a CU (<= 80 KB of LDS, 4 waves, 256 registers each): whatever one of them waits for -- a barrier, a DMA
-// landing, its prologue or its epilogue -- the other one's waves keep the SIMD's matrix pipe busy.
-//   * workgroup = 4 waves = 64 output channels x 32 tiles (2 output rows x 64 columns); wave i owns the transform row
-//     xi = 4i .. 4i+3 for BOTH 32-channel cout blocks: 8 accumulator tiles (128 registers);
-//   * the B operand of v_mfma_f32_32x32x2_f32 -- lane (tile t, half h) supplies V[xi][channel 2kp + h][tile t] -- is what that
-//     lane can compute itself from the raw input rows in LDS: row i of B^T d needs only TWO patch rows (d0-d2, d1+d2, d2-d1,
-//     d1-d3), so a patch costs 6 ds_read_b64 + 8 VALU, placed by hand in the shadow of the 64-cycle MFMAs of the previous
-//     chunk.  V never goes through LDS: no V buffer, no V writes, no B-operand reads, no transform barrier;
-//   * the A operands (pre-transformed weights U) of a wave are ITS OWN slice of U (xi row i): a wave-private LDS ring filled by
-//     that wave's LDS-DMA (no cross-wave hand-over), packed so that a lane's four xi-column values are one ds_read_b128;
-//   * only the raw input rows (4 rows x 72 columns per channel) are shared by the 4 waves: one 4-wave barrier per 4-channel
-//     chunk, placed where every MFMA operand of the next step is already in registers;
-//   * every wave issues the same 6 DMA instructions per chunk (4 of its U ring, 2 of the raw ring; tail chunks, padding lanes
-//     and out-of-image pieces fetch a 16-byte zero page), so one counted `s_waitcnt vmcnt(8)` per chunk is exact;
-//   * the skip tensor of a residual launch is staged by the same DMA slots: the U-ring loads that would fetch chunks nch and
-//     nch+1 fetch the wave's 32 channels x 64 columns of the skip row instead (no registers, no extra instructions);
-//   * the sign of xi row 2 (d2-d1 = -(d1-d2)) is folded into the packed weights, so every row transform is one fma(+-1).
-// Epilogue: column transform in registers (M A), the 4 waves exchange their xi-row contributions through LDS (48 KB),
-// wave i finalises output row i&1 of cout block i>>1: bias, ReLU, skip, PixelShuffle, stores.
-// LDS: U rings 4 x 3 x 4 KB + raw ring 4 x 5 KB + 1 KB dump = 69 KB.  Requires W % 4 == 0 and 16-byte aligned tensors.
+// What the LDS-DMA kernel (conv3x3_wino_dma.hip) leaves on the table (profiles/r01_wino_dma_experiments.log, matrix pipe busy
+// 51 %): every 8-channel chunk pays two workgroup barriers around an LDS round trip of the transformed inputs V, every tile
+// pays an exposed prologue (cold DMA) and an epilogue in which the SIMD partners exchange half of the output transform
+// through LDS.  Two intermediate designs of this round are logged in profiles/r02_winov_v1_stamps.log (xi-row waves with an
+// LDS exchange epilogue; 4-wave workgroups two per CU -- DMA-latency-bound).  This kernel:
+//   * MFMA tile v_mfma_f32_16x16x4_f32 (16 channels x 16 tiles x 4 input channels).  A wave owns 32 output channels x 16 tiles
+//     for ALL 16 transform points: 2 x 16 accumulator tiles x 4 registers = 128 registers.  Lane (tile t = lane & 15,
+//     channel kq = lane >> 4) supplies the B operand V[xi][4 s + kq][t] for every xi -- exactly the 4x4 input transform of ITS
+//     patch, which it computes itself from the raw rows in LDS (12 ds_read_b64 + 32 VALU per 32 MFMAs, placed by hand between
+//     the MFMAs of the previous step).  V never goes through LDS: no V buffer, no transform barrier;
+//   * all 16 transform points of a (channel, tile) pair sit in one lane, so the output transform A^T M A is lane-local:
+//     no exchange through LDS, no epilogue barrier -- the epilogue is ~200 VALU and the stores;
+//   * the workgroup (8 waves = 2 channel halves x 4 tile quarters = 64 channels x 64 tiles, one per CU) is PERSISTENT: it walks
+//     a contiguous range of (image, cout group, tile) items and treats their chunks as ONE stream.  U (pre-transformed weights,
+//     32 KB per 8-channel chunk, shared by the 8 waves) and the raw input rows (13.5 KB per chunk) arrive by LDS-DMA in rings
+//     of 3 and 4 slots; the DMA for chunk G+2 / G+4 is issued during chunk G whatever item it belongs to, so only the first
+//     item of a workgroup sees a cold prologue;
+//   * ONE barrier per chunk, placed mid-chunk where the MFMA operands of the following step are already in registers; every wave
+//     issues the same 6 DMA instructions per chunk (padding lanes, out-of-image pieces, channel tails and the slots past the end
+//     of the stream fetch a 16-byte zero page), so the counted `s_waitcnt vmcnt(2)` before the barrier is exact;
+//   * the A operands are packed so that a lane's four consecutive transform points are one ds_read_b128, lane-linear (no bank
+//     conflicts), requested one 8-MFMA group ahead.
+// LDS: U ring 3 x 32 KB + raw ring 4 x 14 KB + 1 KB dump = 153 KB.  Requires W % 4 == 0 and 16-byte aligned x / packed_w.
 #include "kmsr_common.h"
 
 #include <algorithm>
@@ -31,67 +31,64 @@
 namespace kmsr {
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-constexpr int VCK = 4;                 // input channels per chunk
+constexpr int VCK = 8;                 // input channels per chunk (2 MFMA steps of 4)
 constexpr int VCO = 64;                // output channels per workgroup
-constexpr int TCOLS = 32;              // tiles per workgroup: 1 x 32  (output 2 rows x 64 cols)
-constexpr int kThreads = 256;
-constexpr int UWF = 4 * VCK * 64;      // 1024 floats = 4 KB: one wave's slice of U per chunk ([q = cbk*2 + kp][lane][j])
-constexpr int VUF = 4 * UWF;           // 4096 floats of U per chunk and cout group
-constexpr int NU = 3;                  // U ring slots per wave (a chunk's U is requested 2 chunks ahead)
-constexpr int UINSTR = 4;              // U DMA instructions per wave and chunk
-constexpr int RROWS = 4;               // input rows of a tile row
+constexpr int TROWS = 2, TCOLS = 32;   // tiles per workgroup: 2 x 32  (output 4 rows x 64 cols)
+constexpr int kThreads = 512;
+constexpr int VUF = 16 * VCK * VCO;    // 8192 floats = 32 KB of U per chunk: [step 2][cb16 4][m 4][lane 64][jj 4]
+constexpr int NU = 3;                  // U ring slots (chunk G+2 is requested during chunk G)
+constexpr int DMA_WAVES = 8;                       // every wave issues its share of the DMA (concentrating it on one wave per SIMD was slower: 439 vs 394 us)
+                                                   // partner (wave + 4) keeps the matrix pipe to itself, so the ~130 cycles an LDS-DMA
+                                                   // instruction costs its issuer are not lost (both partners issuing at once: -47 us)
+constexpr int UINSTR = VUF / 256 / DMA_WAVES;      // 8 U DMA instructions per issuing wave and chunk
+constexpr int RROWS = 2 * TROWS + 2;   // 6 input rows
 constexpr int RQ = (2 * TCOLS + 8) / 4;            // 18 float4 per row segment: columns tx0-4 .. tx0+67
 constexpr int RCOLS = 4 * RQ;                      // 72
-constexpr int RLANES = VCK * RROWS * RQ;           // 288 lane-loads per chunk = 4.5 wave instructions
-constexpr int RINSTR = 2;                          // raw DMA instructions per wave and chunk (8 slots, 5 real, 3 to the dump)
-constexpr int RREAL = (RLANES + 63) / 64;          // 5
-constexpr int RAWF = RREAL * 256;                  // 1280 floats = 5 KB per ring slot
-constexpr int NRAW = 4;                            // raw ring slots: rows are requested 4 chunks ahead of their transform
-constexpr int OFF_U = 0, OFF_R = 4 * NU * UWF, OFF_DUMP = OFF_R + NRAW * RAWF, LOOP_FLOATS = OFF_DUMP + 256;
-constexpr int XCHF = 4 * 2 * 16 * 64 * 2;          // epilogue exchange: [wave][cout block][reg][lane] float2 = 64 KB
-constexpr int OFF_B = LOOP_FLOATS > XCHF ? LOOP_FLOATS : XCHF;
-constexpr int LDS_FLOATS = OFF_B + VCO;
-static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups must fit one CU's 160 KB of LDS");
+constexpr int RLANES = VCK * RROWS * RQ;           // 864 lane-loads per chunk = 13.5 wave instructions
+constexpr int RINSTR = 2;                          // raw DMA instructions per wave and chunk (16 slots, 14 real, 2 to the dump)
+constexpr int RREAL = (RLANES + 63) / 64;          // 14
+constexpr int RAWF = RREAL * 256;                  // 3584 floats = 14 KB per ring slot
+constexpr int NRAW = 4;                            // raw ring slots (chunk G+4 is requested during chunk G)
+constexpr int MAX_BIAS = 1024;                     // the whole bias vector sits in LDS (read in the epilogue without touching vmcnt)
+constexpr int OFF_U = 0, OFF_R = NU * VUF, OFF_DUMP = OFF_R + NRAW * RAWF, OFF_B = OFF_DUMP + 256, LDS_FLOATS = OFF_B + MAX_BIAS;
+static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget of one CU");
 
 __device__ __attribute__((aligned(16))) float g_zero_page[4];   // zero-initialised: source of every padded 16-byte piece
 
 struct WinoVParams {
     int N, Cin, H, W, Cout;            // stride 1: Ho = H, Wo = W
-    int tiles_x, tiles, cgs, nchunks, relu, n_blocks;
-    int stagger_mode, stagger_sleeps;  // EXPERIMENT (to be hard-wired): which first-generation workgroups start late, and by how much
+    int tiles_x, tiles, cgs, nchunks, relu, n_items;
 };
 
-// packed[cg][chunk][i][q = cbk*2 + kp][lane = half*32 + l32][j] = s_i * (G g G^T)[xi = 4i + j] for
-// (co, ci) = (cg*64 + cbk*32 + l32, chunk*4 + 2kp + half), zero padded; s_2 = -1 (see the header), else +1
+// packed[cg][chunk][step][cb16][m][lane][jj] = (G g G^T)[xi = 4m + jj] for
+// (co, ci) = (cg*64 + cb16*16 + (lane & 15), chunk*8 + step*4 + (lane >> 4)), zero padded
 __global__ void winov_pack_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ packed, int nchunks,
                                   long long total) {
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int j = (int)(idx & 3);
+        const int jj = (int)(idx & 3);
         const int lane = (int)((idx >> 2) & 63);
-        const int q = (int)((idx >> 8) & 3);
-        const int i = (int)((idx >> 10) & 3);
-        const int chunk = (int)((idx >> 12) % nchunks);
-        const int cg = (int)((idx >> 12) / nchunks);
-        const int half = lane >> 5, l32 = lane & 31, cbk = q >> 1, kp = q & 1;
-        const int cog = cg * VCO + cbk * 32 + l32, cig = chunk * VCK + 2 * kp + half;
+        const int m = (int)((idx >> 8) & 3);
+        const int cb16 = (int)((idx >> 10) & 3);
+        const int step = (int)((idx >> 12) & 1);
+        const int chunk = (int)((idx >> 13) % nchunks);
+        const int cg = (int)((idx >> 13) / nchunks);
+        const int cog = cg * VCO + cb16 * 16 + (lane & 15), cig = chunk * VCK + step * 4 + (lane >> 4);
         float v = 0.f;
         if (cog < Cout && cig < Cin) {
             const float* g = w + ((long long)cog * Cin + cig) * 9;
             // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]];  U = G g G^T
-            float row[3];   // (G g)[i][:]
+            float row[3];   // (G g)[m][:]
             for (int c = 0; c < 3; ++c) {
                 const float g0 = g[0 * 3 + c], g1 = g[1 * 3 + c], g2 = g[2 * 3 + c];
-                row[c] = i == 0 ? g0 : (i == 1 ? 0.5f * (g0 + g1 + g2) : (i == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+                row[c] = m == 0 ? g0 : (m == 1 ? 0.5f * (g0 + g1 + g2) : (m == 2 ? 0.5f * (g0 - g1 + g2) : g2));
             }
-            v = j == 0 ? row[0] : (j == 1 ? 0.5f * (row[0] + row[1] + row[2]) : (j == 2 ? 0.5f * (row[0] - row[1] + row[2]) : row[2]));
-            if (i == 2) v = -v;
+            v = jj == 0 ? row[0] : (jj == 1 ? 0.5f * (row[0] + row[1] + row[2]) : (jj == 2 ? 0.5f * (row[0] - row[1] + row[2]) : row[2]));
         }
         packed[idx] = v;
     }
@@ -101,6 +98,7 @@ __global__ void winov_pack_kernel(const float* __restrict__ w, int Cin, int Cout
 // hipcc then KNOWS the counter state and does not re-wait conservatively for LDS reads that were already retired.
 constexpr int wait_imm(int vm, int lgkm) { return (vm & 15) | ((vm >> 4) << 14) | (7 << 4) | ((lgkm & 15) << 8); }
 #define KMSR_FENCE() asm volatile("" ::: "memory")
+#define KMSR_SB() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ void barrier_lds() {   // LDS hand-over only: does NOT wait for LDS-DMA in flight (counted by the caller)
     KMSR_FENCE();
     __builtin_amdgcn_s_waitcnt(wait_imm(63, 0));
@@ -114,7 +112,7 @@ __device__ __forceinline__ void wait_dma() {      // all but the N newest vector
     KMSR_FENCE();
 }
 
-#define KMSR_SB() __builtin_amdgcn_sched_barrier(0)
+struct PatchPair { f32x2 p[4]; };      // one aligned column pair of the 4 patch rows (4 ds_read_b64)
 
 template <bool PS>
 __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float* __restrict__ xg,
@@ -123,292 +121,308 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
                                                                     const float* __restrict__ res,
                                                                     float* __restrict__ out, WinoVParams p) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
-    const int xr = __builtin_amdgcn_readfirstlane(tid >> 6);            // wave = xi row
-
-    const int nb = p.n_blocks, bq = nb >> 3, br = nb & 7, xcd = blockIdx.x & 7;
-    int bid = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (blockIdx.x >> 3);
-    const int tile = bid % p.tiles;
-    bid /= p.tiles;
-    const int cg = bid % p.cgs;
-    const int n = bid / p.cgs;
-    const int ty0 = (tile / p.tiles_x) * 2, tx0 = (tile % p.tiles_x) * (2 * TCOLS);
-    const int H = p.H, W = p.W;
+    const int tid = threadIdx.x, lane = tid & 63, t16 = lane & 15, kq = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = wv & 1, tq = wv >> 1, tb = tq >> 1, tc0 = 16 * (tq & 1);   // channel half, tile quarter = (tile row, first tile column)
+    const int H = p.H, W = p.W, nch = p.nchunks;
     const long long HW = (long long)H * W;
-    const float* __restrict__ xn = xg + (long long)n * p.Cin * HW;
-    const int nch = p.nchunks;
-    // this wave's slice of the packed weights: chunk k at wme + k * VUF
-    const float* __restrict__ wme = wpk + (long long)cg * nch * VUF + xr * UWF + lane * 4;
+
+    // contiguous item range of this workgroup; workgroups that share an XCD (id % 8) get neighbouring ranges
+    const int nwg = gridDim.x, bq = nwg >> 3, br = nwg & 7, xcd = blockIdx.x & 7;
+    const int vb = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (blockIdx.x >> 3);
+    const int per = (p.n_items + nwg - 1) / nwg;
+    const int it0 = vb * per, it1 = min(it0 + per, p.n_items);
+    if (it0 >= it1) return;                                  // block-uniform
+    const int T = (it1 - it0) * nch;                         // chunks in this workgroup's stream
+
+    const bool dma_wave = wv < DMA_WAVES;                    // wave-uniform
     const float* zero_page = g_zero_page;
     asm volatile("" : "+s"(zero_page));                      // resolved once (the GOT load would otherwise be repeated per chunk)
 
-    {   // EXPERIMENT: de-phase the two workgroups that share a CU (equal lifetimes keep whatever phase they start with)
-        bool late = false;
-        const int b = blockIdx.x;
-        if (p.stagger_mode == 1) late = b >= 256 && b < 512;
-        else if (p.stagger_mode == 2) late = b < 512 && ((b >> 3) & 1);
-        else if (p.stagger_mode == 3) late = b < 512 && ((b >> 8) & 1) == 0 && ((b >> 3) & 1);
-        else if (p.stagger_mode == 4) late = b >= 256 && b < 512;
-        if (late)
-            for (int i = 0; i < p.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(32);
-        if (p.stagger_mode == 4 && b < 256)                  // mode 4: random-ish phase for everyone in the first generation
-            for (int i = 0; i < (b * 7) % (2 * p.stagger_sleeps + 1); ++i) __builtin_amdgcn_s_sleep(16);
-    }
-    // this wave finalises output row xr & 1 of cout block xr >> 1
-    const int orow = xr & 1, ocb = xr >> 1;
-    const int ry = ty0 + orow, rx0 = tx0 + 2 * l32;
-
-    // ---- DMA maps.  Raw tile (shared), lane-linear: L = (2 xr + i) * 64 + lane  <-> (segment = L / 18 = channel * 4 + row,
-    //      q = L % 18 = float4 within the row); LDS offset = 4 L floats; instruction slots 5..7 are padding and go to the dump.
-    int roff[RINSTR], rch[RINSTR];
+    // ---- DMA cursors.  U: chunk gU of the stream = chunk cU of item itU (only its cout group matters).
+    int gU = 0, cU = 0, itU = it0, cgU = (it0 / p.tiles) % p.cgs;
+    const float* usrc = zero_page;                           // source of the chunk being issued (set by part 0)
+    int ustride = 0;
+    auto issue_u = [&](int i0, int i1) {                     // DMA instructions [i0, i1) of chunk gU; the cursor advances after the last one
+        float* ub = lds + OFF_U + (gU % NU) * VUF;
+        if (i0 == 0) {
+            usrc = zero_page;
+            if (gU < T) usrc = wpk + ((long long)cgU * nch + cU) * VUF + (UINSTR * wv * 64 + lane) * 4;   // block-uniform branch
+            ustride = gU < T ? 256 : 0;
+        }
 #pragma unroll
-    for (int i = 0; i < RINSTR; ++i) {
-        const int L = (RINSTR * xr + i) * 64 + lane;
-        const int seg = L / RQ, q = L - seg * RQ, ch = seg / RROWS, row = seg - ch * RROWS;
-        const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * q;
-        const bool ok = L < RLANES && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
-        roff[i] = ok ? (int)(ch * HW + (long long)gy * W + gx) : -1;
-        rch[i] = ch;
-    }
-    auto issue_raw = [&](int chunk) {                        // raw(chunk) -> ring slot chunk % NRAW; past the last chunk: zeros
-        const float* __restrict__ xc = xn + (long long)chunk * VCK * HW;
-        const int cin_left = p.Cin - chunk * VCK;            // <= 0 past the last chunk
-        float* rb = lds + OFF_R + (chunk % NRAW) * RAWF;
+        for (int i = i0; i < i1; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(usrc + i * ustride), (lds_void_t*)(ub + (UINSTR * wv + i) * 256), 16, 0, 0);
+        if (i1 == UINSTR) {
+            ++gU;
+            if (++cU == nch) {
+                cU = 0;
+                ++itU;
+                cgU = (itU / p.tiles) % p.cgs;
+            }
+        }
+    };
+    // raw rows: chunk gR = chunk cR of item itR.  Raw tile, lane-linear: L = (2 wv + i) * 64 + lane <-> (segment = L / 18 =
+    // channel * 6 + row, q = L % 18 = float4 within the row); LDS offset = 4 L floats; instruction slots 14, 15 go to the dump.
+    int gR = 0, cR = 0, itR = it0, tyR = 0, txR = 0;
+    const float* xnR = xg;
+    auto raw_item = [&]() {                                  // scalars of item itR (when the cursor enters a new item)
+        const int tile = itR % p.tiles, n = itR / (p.tiles * p.cgs);
+        tyR = (tile / p.tiles_x) * (2 * TROWS);
+        txR = (tile % p.tiles_x) * (2 * TCOLS);
+        xnR = xg + (long long)n * p.Cin * HW;
+    };
+    raw_item();
+    auto issue_raw = [&]() {
+        const float* __restrict__ xc = xnR + (long long)cR * VCK * HW;
+        const int cin_left = gR < T ? p.Cin - cR * VCK : 0;  // past the end of the stream: zeros
+        float* rb = lds + OFF_R + (gR % NRAW) * RAWF;
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));                     // compute the lane map HERE, per chunk (only the issuing waves pay for it, in
+                                                             // the shadow of their SIMD partners; kept in registers it would be spilled)
 #pragma unroll
         for (int i = 0; i < RINSTR; ++i) {
-            const bool ok = roff[i] >= 0 && rch[i] < cin_left;
-            const float* src = ok ? xc + roff[i] : zero_page;
-            const int slot = RINSTR * xr + i;                // wave-uniform
+            const int L = (RINSTR * wv + i) * 64 + lane_o;
+            const int seg = L / RQ, q = L - seg * RQ, ch = seg / RROWS, row = seg - ch * RROWS;
+            const int gy = tyR - 1 + row, gx = txR - 4 + 4 * q;
+            const bool ok = L < RLANES && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W && ch < cin_left;
+            const float* src = ok ? xc + (ch * HW + (long long)gy * W + gx) : zero_page;
+            const int slot = RINSTR * wv + i;                // wave-uniform
             float* dst = slot < RREAL ? rb + slot * 256 : lds + OFF_DUMP;
             __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
         }
-    };
-    // U ring slot k % NU of this wave <- chunk k of its U slice; k = nch, nch + 1: the two halves of the wave's skip-tensor slice
-    // ([channel 32][column 64] of output row ry, lane = (channel 4 i + lane / 16, columns 4 (lane % 16) ..+3)); beyond: zeros
-    float* uring = lds + OFF_U + xr * (NU * UWF);
-    const int res_c0 = cg * VCO + ocb * 32 + (lane >> 4);    // + 16 half + 4 i
-    const int res_x = tx0 + 4 * (lane & 15);
-    const bool res_ok = !PS && res != nullptr && ry < H && res_x < W;
-    const float* res_me = res_ok ? res + (((long long)n * p.Cout + res_c0) * H + ry) * W + res_x : zero_page;   // + (16 half + 4 i) * HW
-    auto issue_u = [&](int k) {
-        float* ub = uring + (k % NU) * UWF;
-        if (k < nch) {                                       // wave-uniform
-            const float* __restrict__ wk = wme + (long long)k * VUF;
-#pragma unroll
-            for (int i = 0; i < UINSTR; ++i)
-                __builtin_amdgcn_global_load_lds((glb_void_t*)(wk + i * 256), (lds_void_t*)(ub + i * 256), 16, 0, 0);
-        } else if (!PS && res != nullptr && k < nch + 2) {
-            const int c16 = 16 * (k - nch);
-#pragma unroll
-            for (int i = 0; i < UINSTR; ++i) {
-                const bool ok = res_ok && res_c0 + c16 + 4 * i < p.Cout;
-                const float* src = ok ? res_me + (long long)(c16 + 4 * i) * HW : zero_page;
-                __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(ub + i * 256), 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < UINSTR; ++i)
-                __builtin_amdgcn_global_load_lds((glb_void_t*)zero_page, (lds_void_t*)(ub + i * 256), 16, 0, 0);
+        ++gR;
+        if (++cR == nch) {
+            cR = 0;
+            ++itR;
+            if (gR < T) raw_item();
         }
     };
 
-    // ---- input transform of this wave's xi row: lane (tile l32, half) owns channels 2kp + half, kp = 0, 1.
-    //      patch rows r <-> raw rows r; patch columns <-> raw columns 2 l32 + 3 .. + 6, read as the aligned pairs at raw columns
-    //      2 l32 + 2, + 4, + 6.  Row transform t = d[ra] + sb * d[rb]:
-    //      i = 0: d0 - d2;  i = 1: d1 + d2;  i = 2: d1 - d2 (sign folded into U);  i = 3: d1 - d3.
-    const int ra = xr == 0 ? 0 : 1, rbw = xr == 3 ? 3 : 2;
-    const float sb = xr == 1 ? 1.f : -1.f;
-    const int rbase = (half * RROWS + ra) * RCOLS + 2 * l32 + 2;
-    const int rdelta = (rbw - ra) * RCOLS;
-    struct Patch { f32x2 a0, a1, a2, b0, b1, b2; };
-    auto load_patch = [&](const float* rp, int kp) {         // 6 ds_read_b64
-        const float* pa = rp + 2 * kp * RROWS * RCOLS;
-        const float* pb = pa + rdelta;
-        Patch q;
-        q.a0 = *reinterpret_cast<const f32x2*>(pa); q.a1 = *reinterpret_cast<const f32x2*>(pa + 2); q.a2 = *reinterpret_cast<const f32x2*>(pa + 4);
-        q.b0 = *reinterpret_cast<const f32x2*>(pb); q.b1 = *reinterpret_cast<const f32x2*>(pb + 2); q.b2 = *reinterpret_cast<const f32x2*>(pb + 4);
+    // ---- input transform: lane (tile t16 of the wave's 16, channel kq) reads its 4x4 patch from the raw tile: patch rows r <->
+    //      raw rows 2 tb + r; patch columns <-> raw columns 2 tc + 3 .. + 6 (tc = tc0 + t16), read as the aligned pairs at raw columns
+    //      2 tc + 2, + 4, + 6.  V = B^T d B,  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].
+    const int pbase = (kq * RROWS + 2 * tb) * RCOLS + 2 * (tc0 + t16) + 2;          // + step * 4 * RROWS * RCOLS
+    auto load_pair = [&](int g, int step, int k) {           // column pair k (raw columns 2 tc + 2 + 2k, +1) of the 4 patch rows
+        const float* rp = lds + OFF_R + (g % NRAW) * RAWF + pbase + step * (4 * RROWS * RCOLS) + 2 * k;
+        PatchPair q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q.p[r] = *reinterpret_cast<const f32x2*>(rp + r * RCOLS);
         return q;
     };
-    auto rows_of = [&](const Patch& q) {                     // 4 fma: t = d[ra] + sb d[rb]
-        return f32x4{fmaf(sb, q.b0.y, q.a0.y), fmaf(sb, q.b1.x, q.a1.x), fmaf(sb, q.b1.y, q.a1.y), fmaf(sb, q.b2.x, q.a2.x)};
+    // row transform of one patch column: tt[i][c] = (B^T d)[i][c] from the column's four values d0 .. d3
+    auto rows_col = [&](f32x4 (&tt)[4], int c, float d0, float d1, float d2, float d3) {
+        tt[0][c] = d0 - d2;
+        tt[1][c] = d1 + d2;
+        tt[2][c] = d2 - d1;
+        tt[3][c] = d1 - d3;
     };
-    auto cols_of = [&](const f32x4& t, float (&v)[4]) {      // 4 add: V = t B
-        v[0] = t.x - t.z;
-        v[1] = t.y + t.z;
-        v[2] = t.z - t.y;
-        v[3] = t.y - t.w;
+    auto cols_of = [&](const f32x4 (&tt)[4], float (&v)[16], int i0, int i1) {  // v[4i + j] = (t B)[i][j] for i in [i0, i1)
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            v[4 * i + 0] = tt[i][0] - tt[i][2];
+            v[4 * i + 1] = tt[i][1] + tt[i][2];
+            v[4 * i + 2] = tt[i][2] - tt[i][1];
+            v[4 * i + 3] = tt[i][1] - tt[i][3];
+        }
     };
-    auto raw_slot = [&](int chunk) { return lds + OFF_R + (chunk % NRAW) * RAWF + rbase; };
-    auto u_slot = [&](int chunk) { return uring + (chunk % NU) * UWF + lane * 4; };
 
-    f32x16 acc[2][4];      // [cout block][xi column j]
+    f32x4 acc[2][16];      // [channel block of 16][xi]: rows = channels 4 kq + reg, column = tile t16
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.f;
+        for (int x = 0; x < 16; ++x) acc[a][x] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue.  In flight, oldest first: raw(0) raw(1) U(0) raw(2) U(1) raw(3); V(0) needs raw(0), the first MFMAs U(0).
-    issue_raw(0);
-    issue_raw(1);
-    issue_u(0);
-    issue_raw(2);
-    issue_u(1);
-    issue_raw(3);
-    wait_dma<3 * RINSTR + 2 * UINSTR>();                     // raw(0) has landed (this wave's part)
+    // A operands of this wave: U ring slot + ((step*4 + 2 hh + cbi)*4 + m)*256 + lane*4
+    const int abase = (2 * hh) * 4 * 256 + lane * 4;
+    auto a_ptr = [&](int g, int step, int m) { return lds + OFF_U + (g % NU) * VUF + step * (16 * 256) + m * 256 + abase; };
+
+    // bias vector -> LDS (plain loads BEFORE any DMA is in flight; published by the prologue's first barrier)
+    for (int i = tid; i < MAX_BIAS; i += kThreads) lds[OFF_B + i] = (bias && i < p.Cout) ? bias[i] : 0.f;
+
+    // ---- prologue of the stream.  In flight, oldest first: raw(0) raw(1) U(0) raw(2) U(1) raw(3).
+    if (dma_wave) {
+        issue_raw();
+        issue_raw();
+        issue_u(0, UINSTR);
+        issue_raw();
+        issue_u(0, UINSTR);
+        issue_raw();
+    }
+    wait_dma<3 * RINSTR + 2 * UINSTR>();                     // raw(0) has landed (this wave's part; the other waves have nothing in flight)
     barrier_lds();
-    float vA[2][4], vB[2][4];
+    float vA[16], vB[16];
     {
-        const float* rp = raw_slot(0);
-#pragma unroll
-        for (int kp = 0; kp < 2; ++kp) cols_of(rows_of(load_patch(rp, kp)), vA[kp]);
+        const PatchPair k0 = load_pair(0, 0, 0), k1 = load_pair(0, 0, 1), k2 = load_pair(0, 0, 2);
+        f32x4 tt[4];
+        rows_col(tt, 0, k0.p[0].y, k0.p[1].y, k0.p[2].y, k0.p[3].y);
+        rows_col(tt, 1, k1.p[0].x, k1.p[1].x, k1.p[2].x, k1.p[3].x);
+        rows_col(tt, 2, k1.p[0].y, k1.p[1].y, k1.p[2].y, k1.p[3].y);
+        rows_col(tt, 3, k2.p[0].x, k2.p[1].x, k2.p[2].x, k2.p[3].x);
+        cols_of(tt, vA, 0, 4);
     }
     wait_dma<2 * RINSTR + UINSTR>();                         // raw(1), U(0) have landed
-    f32x4 a0[2], a1[2];                                      // A operands of the current / next step ([q = cbk*2 + kp])
-    a0[0] = *reinterpret_cast<const f32x4*>(u_slot(0));
-    a1[0] = *reinterpret_cast<const f32x4*>(u_slot(0) + 2 * 256);
+    barrier_lds();
+    f32x4 a0[2], a1[2];                                      // A operands of the current / next group of 8 MFMAs (cbi = 0, 1)
+    a0[0] = *reinterpret_cast<const f32x4*>(a_ptr(0, 0, 0));
+    a1[0] = *reinterpret_cast<const f32x4*>(a_ptr(0, 0, 0) + 4 * 256);
 
-    // One chunk = 2 steps (channel pairs kp) of 8 MFMAs, hand-placed and pinned with sched_barrier:
-    //   barrier (raw(c+1) of every wave has landed, raw slot c % 4 is free)
-    //   step 0: request patch 0 of chunk c+1 and the A operands / patch of step 1; 8 MFMAs with V(c+1)[0] computed between them;
-    //           this chunk's 6 DMA instructions; counted wait for U(c+1) / raw(c+2)
-    //   step 1: request the A operands of chunk c+1's step 0; 8 MFMAs with V(c+1)[1] computed between them.
-    // The first MFMAs after the barrier have their operands in registers already.
-    auto step = [&](const f32x4& A0, const f32x4& A1, const float (&v)[4], const Patch& pt, float (&vnext)[4]) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[0], v[0], acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[0], v[0], acc[1][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[1], v[1], acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[1], v[1], acc[1][1], 0, 0, 0);
-        KMSR_SB();
-        f32x4 t = rows_of(pt);
-        asm volatile("" : "+v"(t));                          // keep the VALU work HERE (LLVM would sink it to its use in the next chunk)
-        KMSR_SB();
-        acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[2], v[2], acc[0][2], 0, 0, 0);
-        acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[2], v[2], acc[1][2], 0, 0, 0);
-        KMSR_SB();
-        cols_of(t, vnext);
-        asm volatile("" : "+v"(vnext[0]), "+v"(vnext[1]), "+v"(vnext[2]), "+v"(vnext[3]));
-        KMSR_SB();
-        acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[3], v[3], acc[0][3], 0, 0, 0);
-        acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[3], v[3], acc[1][3], 0, 0, 0);
-        KMSR_SB();
-    };
-    auto phase = [&](int chunk, const float (&vc)[2][4], float (&vn)[2][4]) {
-        barrier_lds();
-        const float* rp = raw_slot(chunk + 1);               // (past the last chunk: zeros, harmless)
-        const float* uc = u_slot(chunk);
-        const Patch p0 = load_patch(rp, 0);
-        a0[1] = *reinterpret_cast<const f32x4*>(uc + 1 * 256);
-        a1[1] = *reinterpret_cast<const f32x4*>(uc + 3 * 256);
-        const Patch p1 = load_patch(rp, 1);
-        KMSR_SB();
-        step(a0[0], a1[0], vc[0], p0, vn[0]);
-        issue_u(chunk + 2);
-        issue_raw(chunk + 4);
-        // outstanding, oldest first: raw(c+2) U(c+1) raw(c+3) U(c+2) raw(c+4): the first two must have landed
-        wait_dma<2 * RINSTR + UINSTR>();
-        KMSR_SB();
-        const float* un = u_slot(chunk + 1);                 // wave-private ring: no barrier needed for U
-        a0[0] = *reinterpret_cast<const f32x4*>(un);
-        a1[0] = *reinterpret_cast<const f32x4*>(un + 2 * 256);
-        KMSR_SB();
-        step(a0[1], a1[1], vc[1], p1, vn[1]);
-    };
-    for (int chunk = 0; chunk < nch; chunk += 2) {
-        phase(chunk, vA, vB);
-        if (chunk + 1 < nch) phase(chunk + 1, vB, vA);
+    // 8 MFMAs of transform points 4m .. 4m+3 for both channel blocks
+#define KMSR_MFMA8(M, A0, A1, V)                                                                          \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                     \
+        acc[0][4 * (M) + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32((A0)[jj], (V)[4 * (M) + jj], acc[0][4 * (M) + jj], 0, 0, 0); \
+        acc[1][4 * (M) + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32((A1)[jj], (V)[4 * (M) + jj], acc[1][4 * (M) + jj], 0, 0, 0); \
     }
+    // One step = 32 MFMAs on V(cur) with the NEXT step's V computed between them (hand-placed, pinned with sched_barrier):
+    //   group 0: request two column pairs of the next step's patch (8 ds_read_b64) and the A operands of group 1;   8 MFMAs
+    //   group 1: A operands of group 2;  8 MFMAs + row transform of patch columns 0, 1;  request the third column pair
+    //   group 2: A operands of group 3;  8 MFMAs + row transform of patch columns 2, 3
+    //   group 3: A operands of the next step's group 0;  8 MFMAs + column transform (16 VALU)
+    // (g, step) = this step; (pg, ps) = where the next step's patch lives; (ng, ns) = where the next step's A operands live.
+    auto step = [&](int g, int s, const float (&vc)[16], float (&vn)[16], int pg, int ps, int ng, int ns, bool issue) {
+        PatchPair k0 = load_pair(pg, ps, 0);
+        const PatchPair k1 = load_pair(pg, ps, 1);
+        a0[1] = *reinterpret_cast<const f32x4*>(a_ptr(g, s, 1));
+        a1[1] = *reinterpret_cast<const f32x4*>(a_ptr(g, s, 1) + 4 * 256);
+        KMSR_SB();
+        KMSR_MFMA8(0, a0[0], a1[0], vc);
+        KMSR_SB();
+        if (issue && dma_wave) issue_u(0, UINSTR / 2);       // this chunk's 12 DMA instructions of an issuing wave, four per MFMA group
+        a0[0] = *reinterpret_cast<const f32x4*>(a_ptr(g, s, 2));
+        a1[0] = *reinterpret_cast<const f32x4*>(a_ptr(g, s, 2) + 4 * 256);
+        KMSR_SB();
+        f32x4 tt[4];
+        KMSR_MFMA8(1, a0[1], a1[1], vc);
+        rows_col(tt, 0, k0.p[0].y, k0.p[1].y, k0.p[2].y, k0.p[3].y);
+        rows_col(tt, 1, k1.p[0].x, k1.p[1].x, k1.p[2].x, k1.p[3].x);
+        asm volatile("" : "+v"(tt[0]), "+v"(tt[1]), "+v"(tt[2]), "+v"(tt[3]));     // keep the VALU work HERE (LLVM would sink it)
+        KMSR_SB();
+        k0 = load_pair(pg, ps, 2);                           // third column pair into the first one's registers
+        if (issue && dma_wave) issue_u(UINSTR / 2, UINSTR);
+        a0[1] = *reinterpret_cast<const f32x4*>(a_ptr(g, s, 3));
+        a1[1] = *reinterpret_cast<const f32x4*>(a_ptr(g, s, 3) + 4 * 256);
+        KMSR_SB();
+        KMSR_MFMA8(2, a0[0], a1[0], vc);
+        rows_col(tt, 2, k1.p[0].y, k1.p[1].y, k1.p[2].y, k1.p[3].y);
+        rows_col(tt, 3, k0.p[0].x, k0.p[1].x, k0.p[2].x, k0.p[3].x);
+        asm volatile("" : "+v"(tt[0]), "+v"(tt[1]), "+v"(tt[2]), "+v"(tt[3]));
+        KMSR_SB();
+        if (issue && dma_wave) issue_raw();
+        a0[0] = *reinterpret_cast<const f32x4*>(a_ptr(ng, ns, 0));
+        a1[0] = *reinterpret_cast<const f32x4*>(a_ptr(ng, ns, 0) + 4 * 256);
+        KMSR_SB();
+        KMSR_MFMA8(3, a0[1], a1[1], vc);
+        cols_of(tt, vn, 0, 4);
+#pragma unroll
+        for (int x = 0; x < 16; ++x) asm volatile("" : "+v"(vn[x]));
+        KMSR_SB();
+    };
 
-    // ---- epilogue.  Column transform of this wave's xi row: MA[b] = sum_j M[j] A[j][b], A^T = [[1,1,1,0],[0,1,-1,-1]].
-    //      Row transform across the 4 waves: Y[0][b] = MA_0 + MA_1 + MA_2, Y[1][b] = MA_1 - MA_2 - MA_3
-    //      (xi row 2: U and V both carry the folded sign, so the accumulators hold M itself).
-    f32x2 ma[2][16];
+    // ---- epilogue of one item: lane-local output transform, bias / ReLU / skip / PixelShuffle, stores, accumulators cleared
+    // ---- epilogue of one item: lane-local output transform, bias / ReLU / skip / PixelShuffle, stores, accumulators cleared.
+    // Skip tensor: plain loads to registers, placed so that vmcnt (which retires in order) never makes them wait for fresh DMA
+    // or for stores: channel block 0's values are requested right after the last chunk's barrier, BEFORE that chunk's DMA
+    // instructions; channel block 1's after block 0's outputs are computed (its accumulators are dead) and BEFORE block 0's stores.
+    struct ItemPos { int n, cg, y0, x0; };
+    auto item_pos = [&](int item) {
+        const int tile = item % p.tiles, rest = item / p.tiles;
+        return ItemPos{rest / p.cgs, rest % p.cgs, (tile / p.tiles_x) * (2 * TROWS) + 2 * tb,
+                       (tile % p.tiles_x) * (2 * TCOLS) + 2 * (tc0 + t16)};   // this lane's 2x2 output pixels: rows y0, y0+1, columns x0, x0+1
+    };
+    auto fetch_residual = [&](const ItemPos& ip, int cbi, f32x2 (&rr)[2][4]) {
+        if constexpr (!PS) {
+            if (res) {                                                     // block-uniform
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const float m0 = acc[cb][0][reg], m1 = acc[cb][1][reg], m2 = acc[cb][2][reg], m3 = acc[cb][3][reg];
-            ma[cb][reg] = f32x2{m0 + m1 + m2, m1 - m2 - m3};
-        }
-    wait_dma<0>();                                           // every DMA of this wave has landed (incl. the skip-tensor halves)
-    // skip values of this wave's outputs, [4g + r] <-> channel co0(g) + r, pixel pair (ry, rx0 .. rx0+1), from its U ring
-    f32x2 rres[16];
-    const bool has_res = !PS && res != nullptr;              // block-uniform
-    if (has_res) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c32 = 8 * g + 4 * half + r;        // channel within the wave's 32; half (c32 >> 4) sits in ring slot (nch + half) % NU
-                const float* slot = uring + ((nch + (g >> 1)) % NU) * UWF;
-                rres[4 * g + r] = *reinterpret_cast<const f32x2*>(slot + (c32 & 15) * 64 + 2 * l32);
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = ip.cg * VCO + (2 * hh + cbi) * 16 + 4 * kq + r;
+                        const bool ok = ip.x0 < W && ip.y0 + a < H && co < p.Cout;
+                        const long long o = (((long long)ip.n * p.Cout + co) * H + ip.y0 + a) * W + ip.x0;
+                        rr[a][r] = *reinterpret_cast<const f32x2*>(res + (ok ? o : 0));   // out-of-range lanes are masked at the store
+                    }
             }
-    }
-    barrier_lds();                                           // every wave is done with the rings: the exchange buffer may overwrite them
-    f32x2* xch = reinterpret_cast<f32x2*>(lds);              // [wave][cout block][reg][lane]
-    float* sbias = lds + OFF_B;
-    if (tid < VCO) {
-        const int co = cg * VCO + tid;
-        sbias[tid] = (bias && co < p.Cout) ? bias[co] : 0.f;
-    }
-    f32x2 keep[16];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            if (cb == ocb) keep[reg] = ma[cb][reg];          // wave-uniform select
-            // (xi rows 0 and 3 enter only one output row: their own cout block's part is needed by nobody else)
-            if (!(cb == ocb && (xr == 0 || xr == 3))) xch[((xr * 2 + cb) * 16 + reg) * 64 + lane] = ma[cb][reg];
         }
-    }
-    __syncthreads();
-    // Y[orow] = sum over xi rows i' of AT[orow][i'] * MA_i':  row 0: +0 +1 +2;  row 1: +1 -2 -3.  Own contribution from registers.
-    int pa_, pb_;
-    float ca, cb_, cs;                                       // coefficients of partner a, partner b, self
-    if (orow == 0) {          // waves xr = 0 (partners 1, 2) and xr = 2 (partners 0, 1): all +1
-        pa_ = xr == 0 ? 1 : 0;
-        pb_ = xr == 0 ? 2 : 1;
-        ca = 1.f; cb_ = 1.f; cs = 1.f;
-    } else {                  // waves xr = 1 (self +1, partners 2: -1, 3: -1) and xr = 3 (self -1, partners 1: +1, 2: -1)
-        pa_ = xr == 1 ? 2 : 1;
-        pb_ = xr == 1 ? 3 : 2;
-        ca = xr == 1 ? -1.f : 1.f; cb_ = -1.f; cs = xr == 1 ? 1.f : -1.f;
-    }
-    const f32x2* xa = xch + ((pa_ * 2 + ocb) * 16) * 64 + lane;
-    const f32x2* xb = xch + ((pb_ * 2 + ocb) * 16) * 64 + lane;
-    const int y = ry, x0 = rx0;
-    const bool pok2 = y < H && x0 < W;                        // (x0, x0+1) is an aligned pair: inside or outside as a whole
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int co0 = cg * VCO + ocb * 32 + 8 * g + 4 * half;              // channels co0 .. co0+3 <-> registers 4g .. 4g+3
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + ocb * 32 + 8 * g + 4 * half);
+    };
+    auto outputs_of = [&](const ItemPos& ip, int cbi, f32x2 (&Y)[2][4]) {  // [output row a][register r] = (column x0, column x0+1)
+        const int co0 = ip.cg * VCO + (2 * hh + cbi) * 16 + 4 * kq;        // channels co0 .. co0+3 <-> registers 0 .. 3
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds + OFF_B + co0);   // co0 % 4 == 0; zeros past Cout
         const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-        f32x2 Y[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const f32x2 oa = xa[(4 * g + r) * 64], ob = xb[(4 * g + r) * 64];
-            Y[r] = f32x2{cs * keep[4 * g + r].x + ca * oa.x + cb_ * ob.x + bb[r], cs * keep[4 * g + r].y + ca * oa.y + cb_ * ob.y + bb[r]};
-            if (p.relu) Y[r] = f32x2{fmaxf(Y[r].x, 0.f), fmaxf(Y[r].y, 0.f)};
+            float ma[4][2];                                                // column transform: MA[i][b] = sum_j M[i][j] A[j][b], A^T = [[1,1,1,0],[0,1,-1,-1]]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float m0 = acc[cbi][4 * i + 0][r], m1 = acc[cbi][4 * i + 1][r], m2 = acc[cbi][4 * i + 2][r], m3 = acc[cbi][4 * i + 3][r];
+                ma[i][0] = m0 + m1 + m2;
+                ma[i][1] = m1 - m2 - m3;
+            }
+            Y[0][r] = f32x2{ma[0][0] + ma[1][0] + ma[2][0] + bb[r], ma[0][1] + ma[1][1] + ma[2][1] + bb[r]};
+            Y[1][r] = f32x2{ma[1][0] - ma[2][0] - ma[3][0] + bb[r], ma[1][1] - ma[2][1] - ma[3][1] + bb[r]};
+            if (p.relu) {
+                Y[0][r] = f32x2{fmaxf(Y[0][r].x, 0.f), fmaxf(Y[0][r].y, 0.f)};
+                Y[1][r] = f32x2{fmaxf(Y[1][r].x, 0.f), fmaxf(Y[1][r].y, 0.f)};
+            }
         }
+#pragma unroll
+        for (int x = 0; x < 16; ++x) acc[cbi][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_outputs = [&](const ItemPos& ip, int cbi, const f32x2 (&Y)[2][4], const f32x2 (&rr)[2][4]) {
+        const int co0 = ip.cg * VCO + (2 * hh + cbi) * 16 + 4 * kq;
+        const bool xok = ip.x0 < W;                                        // (x0, x0+1) is an aligned pair: inside or outside as a whole
         if constexpr (PS) {
-            // conv channel q = co0 + r -> out[n, q>>2, 2y + (r>>1), 2x + (r&1)]: this lane writes rows 2y, 2y+1, cols 2x0 .. 2x0+3
-            if (pok2 && co0 < p.Cout) {
+            // conv channel q = co0 + r -> out[n, q >> 2, 2y + (r >> 1), 2x + (r & 1)]: per conv row y this lane writes the two
+            // rows 2y, 2y+1 of out channel co0 / 4, columns 2 x0 .. 2 x0 + 3
+            if (xok && co0 < p.Cout) {
                 const long long W2 = 2ll * W;
-                float* o = out + (((long long)n * (p.Cout >> 2) + (co0 >> 2)) * (2ll * H) + 2 * y) * W2 + 2 * x0;
-                *reinterpret_cast<f32x4*>(o) = f32x4{Y[0].x, Y[1].x, Y[0].y, Y[1].y};
-                *reinterpret_cast<f32x4*>(o + W2) = f32x4{Y[2].x, Y[3].x, Y[2].y, Y[3].y};
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    if (ip.y0 + a < H) {
+                        float* o = out + (((long long)ip.n * (p.Cout >> 2) + (co0 >> 2)) * (2ll * H) + 2 * (ip.y0 + a)) * W2 + 2 * ip.x0;
+                        *reinterpret_cast<f32x4*>(o) = f32x4{Y[a][0].x, Y[a][1].x, Y[a][0].y, Y[a][1].y};
+                        *reinterpret_cast<f32x4*>(o + W2) = f32x4{Y[a][2].x, Y[a][3].x, Y[a][2].y, Y[a][3].y};
+                    }
             }
         } else {
-            const long long base = ((long long)n * p.Cout + co0) * HW + (long long)y * W + x0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                f32x2 v = Y[r];
-                if (has_res) v = f32x2{v.x + rres[4 * g + r].x, v.y + rres[4 * g + r].y};   // out-of-range pieces were staged as zeros
-                if (pok2 && co0 + r < p.Cout) *reinterpret_cast<f32x2*>(out + base + r * HW) = v;
-            }
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f32x2 v = Y[a][r];
+                    if (res) v = f32x2{v.x + rr[a][r].x, v.y + rr[a][r].y};
+                    if (xok && ip.y0 + a < H && co0 + r < p.Cout)
+                        *reinterpret_cast<f32x2*>(out + (((long long)ip.n * p.Cout + co0 + r) * H + ip.y0 + a) * W + ip.x0) = v;
+                }
+        }
+    };
+
+    // ---- the chunk stream.  Chunk G: step 0 multiplies V(G, channels 0-3) and computes V(G, channels 4-7); the mid-chunk barrier
+    //      publishes U(G+1) / raw(G+2) and frees U(G-1)'s and raw(G)'s slots; step 1 multiplies V(G, 4-7), issues the DMA of
+    //      U(G+2) / raw(G+4) and computes V(G+1, 0-3).
+    int item = it0, c = 0;
+    for (int g = 0; g < T; ++g) {
+        step(g, 0, vA, vB, g, 1, g, 1, false);
+        wait_dma<RINSTR>();                                  // outstanding: U(g+1), raw(g+3): everything but the newest raw chunk has landed
+        barrier_lds();
+        f32x2 rr0[2][4];
+        ItemPos ip{};
+        if (c + 1 == nch) {                                  // block-uniform
+            ip = item_pos(item);
+            fetch_residual(ip, 0, rr0);
+        }
+        step(g, 1, vB, vA, g + 1, 0, g + 1, 0, true);
+        if (++c == nch) {                                    // block-uniform
+            c = 0;
+            f32x2 Y0[2][4], Y1[2][4], rr1[2][4];
+            outputs_of(ip, 0, Y0);
+            fetch_residual(ip, 1, rr1);
+            store_outputs(ip, 0, Y0, rr0);
+            outputs_of(ip, 1, Y1);
+            store_outputs(ip, 1, Y1, rr1);
+            ++item;
         }
     }
+#undef KMSR_MFMA8
 }
 #undef KMSR_SB
 #undef KMSR_FENCE
@@ -440,29 +454,34 @@ extern "C" int kmsr_conv3x3_winov_fwd_f32(const kmsr_conv3x3_desc* d, const floa
     if (d->stride != 1) return fail(KMSR_E_UNSUPPORTED, "winograd conv needs stride 1");
     if (d->W % 4) return fail(KMSR_E_UNSUPPORTED, "winograd-vreg conv needs W %% 4 == 0 (W=%d): rows are fetched as aligned 16-byte pieces", d->W);
     if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(packed_w) % 16 || reinterpret_cast<uintptr_t>(out) % 8 ||
-        reinterpret_cast<uintptr_t>(residual) % 16)
-        return fail(KMSR_E_BADARG, "winograd-vreg conv needs 16-byte aligned input / weights / residual and 8-byte aligned output");
+        reinterpret_cast<uintptr_t>(residual) % 8)
+        return fail(KMSR_E_BADARG, "winograd-vreg conv needs 16-byte aligned input / weights and 8-byte aligned output / residual");
     if (d->pixel_shuffle && (d->Cout % 4)) return fail(KMSR_E_SHAPE, "pixel_shuffle needs Cout %% 4 == 0 (Cout=%d)", d->Cout);
     if (d->pixel_shuffle && residual) return fail(KMSR_E_BADARG, "residual is not supported together with pixel_shuffle");
     if (!x || !packed_w || !out) return fail(KMSR_E_BADARG, "null tensor pointer");
-    if ((long long)d->H * d->W * VCK >= (1ll << 31)) return fail(KMSR_E_UNSUPPORTED, "image plane exceeds 2^29 elements");
+    if ((long long)d->H * d->W * VCK >= (1ll << 31)) return fail(KMSR_E_UNSUPPORTED, "image plane exceeds 2^28 elements");
     WinoVParams p{};
     p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
     p.tiles_x = ceil_div(d->W, 2 * TCOLS);
-    p.tiles = p.tiles_x * ceil_div(d->H, 2);
+    p.tiles = p.tiles_x * ceil_div(d->H, 2 * TROWS);
     p.cgs = ceil_div(d->Cout, VCO);
     p.nchunks = ceil_div(d->Cin, VCK);
     p.relu = d->relu;
-    const long long nblocks = (long long)p.tiles * p.cgs * d->N;
-    if (nblocks > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv grid too large");
-    p.n_blocks = (int)nblocks;
-    p.stagger_mode = (int)(d->flags & 0xF);
-    p.stagger_sleeps = (int)((d->flags >> 4) & 0xFF);
+    const long long nitems = (long long)p.tiles * p.cgs * d->N;
+    if (nitems > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv grid too large");
+    p.n_items = (int)nitems;
+    // persistent workgroups: one per CU, each walks ceil(items / grid) consecutive items
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int grid = (int)std::min<long long>(nitems, cus);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (d->pixel_shuffle)
-        conv3x3_winov_kernel<true><<<p.n_blocks, kThreads, 0, stream>>>(x, packed_w, bias, residual, out, p);
+        conv3x3_winov_kernel<true><<<grid, kThreads, 0, stream>>>(x, packed_w, bias, residual, out, p);
     else
-        conv3x3_winov_kernel<false><<<p.n_blocks, kThreads, 0, stream>>>(x, packed_w, bias, residual, out, p);
+        conv3x3_winov_kernel<false><<<grid, kThreads, 0, stream>>>(x, packed_w, bias, residual, out, p);
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
 }
