@@ -174,7 +174,7 @@ class DegradeSRWorkload:
         #   (no channel / tile padding: 64 channels, 256 % 64 == 0).  roofline.frac is issued / peak: <= 1 by construction.
         self.body_algo = pick_algo(64, 64, 1, w, self.net.use_winograd)
         self.body_flops_per_launch = 2.0 * 9 * batch * 64 * 64 * h * w
-        self.body_issue_ratio = {"direct": 1.0, "winograd": 1 / 2.25, "winograd_dma": 1 / 2.25}[self.body_algo]
+        self.body_issue_ratio = {"direct": 1.0, "winograd": 1 / 2.25, "winograd_vreg": 1 / 2.25}[self.body_algo]
         # degradation kernel: algorithmic bytes per patch = HR read once + LR written once + taps
         self.deg_bytes_per_launch = batch * (4 * C * self.H * self.W + 4 * C * h * w + 4 * C * 13 * 13)
         self._record = False
@@ -216,11 +216,11 @@ class DegradeSRWorkload:
         kernel_ms = sum(ms) / max(len(ms), 1)
         algorithmic = self.body_flops_per_launch / (kernel_ms * 1e-3) / 1e12
         issued = algorithmic * self.body_issue_ratio
-        traffic = static_traffic("conv3x3_winod")
-        kname = {"winograd_dma": "conv3x3_winod_kernel<false>", "winograd": "conv3x3_wino_kernel<false>",
+        traffic = static_traffic("conv3x3_winov")
+        kname = {"winograd_vreg": "conv3x3_winov_kernel<false>", "winograd": "conv3x3_wino_kernel<false>",
                  "direct": "conv3x3_mfma_kernel<1,false>"}[self.body_algo]
         out = {"bound": "mfma",
-               "kernel": f"{kname} (3x3 conv 64->64 @256x256, batch 16; 33 launches/step; Winograd F(2x2,3x3) on the fp32 MFMA, LDS-DMA staged)",
+               "kernel": f"{kname} (3x3 conv 64->64 @256x256, batch 16; 33 launches/step; Winograd F(2x2,3x3) on the fp32 MFMA, persistent workgroups, LDS-DMA rings)",
                "achieved": round(issued, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                "frac": round(issued / F32_MFMA_PEAK_TFLOPS, 4),
                "what": "achieved = MFMA FLOPs the kernel ISSUES per launch (algorithmic direct-conv FLOPs / 2.25 for Winograd F(2x2,3x3)) "
@@ -319,7 +319,7 @@ class DegradeSRWorkload:
             sr_gpu = self.net(lr0).cpu()
             deltas[tag] = {"psnr_delta_db": round(psnr(sr_gpu, hr0, 100.0) - psnr(sr_cpu, hr0, 100.0), 7),
                            "max_rel_diff": float((sr_gpu - sr_cpu).abs().max() / sr_cpu.abs().max())}
-        self.net.fuse_upsampler = False
+        self.net.fuse_upsampler = True
         return {"value": round(v_all, 3), "unit": "LR patches/s", "cores": cores, "kind": "port",
                 "sample": f"{n_all} patch(es): HR 3x1024x1024 -> LR 256^2 -> SR 1024^2, oracle C degradation + torch-CPU "
                           f"SRNetTorch fp32, {el_all:.1f} s on {cores} threads",
@@ -437,10 +437,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["degrade_sr", "degrade", "train", "sr_bf16"], default="degrade_sr")
-    ap.add_argument("--fuse-upsampler", action="store_true",
-                    help="degrade_sr: time the headline with the collapsed upsampler (one conv5x5+PS4 instead of up1/up2/tail; "
-                         "same outputs).  Off by default: the headline runs every layer as its own kernel and the collapsed "
-                         "form is reported beside it under \"variants\".")
+    ap.add_argument("--layerwise-upsampler", action="store_true",
+                    help="degrade_sr: time the headline with up1 / up2 / tail as three kernels.  Default: the collapsed upsampler (one "
+                         "conv5x5 + PixelShuffle(4) + exact frame strips -- an exact inference-time linear rewrite, pinned against the "
+                         "layer-by-layer path at full size by tests/test_fullsize_gpu.py); the other form is reported under \"variants\".")
     args = ap.parse_args()
 
     from kmsr_amd import dist as kd
@@ -476,8 +476,9 @@ def main():
         el = kd.max_over_ranks(time.perf_counter() - t0, device=device)     # slowest rank defines the job's time
         return el, ev0.elapsed_time(ev1) / steps
 
-    if args.workload == "degrade_sr" and args.fuse_upsampler:
-        wl.net.fuse_upsampler = True
+    fuse = args.workload == "degrade_sr" and not args.layerwise_upsampler
+    if args.workload == "degrade_sr":
+        wl.net.fuse_upsampler = fuse
         for _ in range(2):
             wl.step()
     # the headline: EXACTLY args.steps steps, no per-kernel instrumentation inside
@@ -491,21 +492,20 @@ def main():
         wl.instrument(False)
         instrumented = round(el_i / args.steps * 1e3, 4)
     variants = None
-    if args.workload == "degrade_sr" and not args.fuse_upsampler:
-        # same job with the upsampler collapsed (identical outputs within fp32 rounding, tests/test_fullsize_gpu.py); reported
-        # beside the headline, never as `value`
-        wl.net.fuse_upsampler = True
+    if args.workload == "degrade_sr":
+        # the same job with the other upsampler form (identical outputs within fp32 rounding, tests/test_fullsize_gpu.py)
+        wl.net.fuse_upsampler = not fuse
         for _ in range(2):
             wl.step()
         el2, _ = timed(args.steps)
-        wl.net.fuse_upsampler = False
-        variants = {"collapsed_upsampler": {
+        wl.net.fuse_upsampler = fuse
+        f2 = wl.issued_mfma_flops_per_step(not fuse)
+        variants = {("layerwise_upsampler" if fuse else "collapsed_upsampler"): {
             "value": round(wl.patches_per_step * args.steps * world / el2, 2), "unit": "LR patches/s",
             "ms_per_step": round(el2 / args.steps * 1e3, 4),
-            "what": "up1/PS/up2/PS/tail (linear) run as ONE conv5x5 64->48 + PixelShuffle(4) launch + exact 4-px frame strips; "
-                    "same SR output (<= 2e-5 of scale at full size, tests/test_fullsize_gpu.py)",
-            "issued_mfma_flops_per_step": wl.issued_mfma_flops_per_step(True),
-            "issued_mfma_tflops": round(wl.issued_mfma_flops_per_step(True) * args.steps * world / el2 / 1e12, 2)}}
+            "what": "up1/PS/up2/PS/tail (linear) as three conv3x3 launches" if fuse else
+                    "up1/PS/up2/PS/tail run as ONE conv5x5 64->48 + PixelShuffle(4) launch + exact 4-px frame strips",
+            "issued_mfma_flops_per_step": f2, "issued_mfma_tflops": round(f2 * args.steps * world / el2 / 1e12, 2)}}
 
     if rank == 0:
         total_patches = wl.patches_per_step * args.steps * world
@@ -532,12 +532,12 @@ def main():
         if instrumented is not None:
             out["instrumented_ms_per_step"] = instrumented
         if args.workload == "degrade_sr":
-            f = wl.issued_mfma_flops_per_step(args.fuse_upsampler)
+            f = wl.issued_mfma_flops_per_step(fuse)
             out["step_mfma"] = {"issued_flops_per_step": f, "issued_tflops": round(f * args.steps * world / elapsed / 1e12, 2),
                                 "frac_of_peak": round(f * args.steps / elapsed / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                                 "algorithmic_flops_per_step": wl.flops_per_patch * wl.B}
         if args.workload == "degrade_sr":
-            out["config"]["upsampler"] = "collapsed conv5x5+PS4" if args.fuse_upsampler else "layer-by-layer"
+            out["config"]["upsampler"] = "collapsed conv5x5+PS4 (exact linear rewrite of up1/PS/up2/PS/tail)" if fuse else "layer-by-layer"
         if variants:
             out["variants"] = variants
         if not args.no_cpu_baseline and world == 1 and hasattr(wl, "cpu_baseline"):

@@ -219,20 +219,15 @@ int kmsr_conv3x3_wino_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int3
 int kmsr_conv3x3_wino_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
                               const float* residual, float* out, void* stream);
 
-/* LDS-DMA variant of the Winograd kernel: same math, epilogues and tolerances; input rows and transformed weights go
- * global -> LDS directly (no register staging), 8-channel chunks (packed layout [ceil(Cout/64)][ceil(Cin/8)][16][8][64]).
- * Needs W % 4 == 0 and 16-byte aligned x / packed_w; everything else is served by kmsr_conv3x3_wino_fwd_f32. */
-size_t kmsr_conv3x3_winod_packed_weight_floats(int32_t Cin, int32_t Cout);
-int kmsr_conv3x3_winod_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int32_t Cin, int32_t Cout, float* packed,
-                                        void* stream);
-int kmsr_conv3x3_winod_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
-                               const float* residual, float* out, void* stream);
-
-/* "V in registers" form of the LDS-DMA Winograd kernel: same math, epilogues, tolerances and preconditions (W % 4 == 0,
- * 16-byte aligned x / packed_w).  The workgroup's 8 waves are (transform row i) x (tile row): each lane computes the MFMA
- * B operand (its tiles' transformed inputs for row i) itself from the raw input rows in LDS, inside the previous chunk's
- * MFMA phase, so the transformed inputs never go through LDS and a chunk costs ONE barrier instead of two.
- * Packed layout [ceil(Cout/64)][ceil(Cin/8)][4 rows][8 (cout block, channel pair)][64 lanes][4 columns]. */
+/* Persistent "V in registers" Winograd kernel (the one the SR net runs; same math, epilogues and tolerances as above).
+ * Needs W % 4 == 0 and 16-byte aligned x / packed_w (rows and weights arrive by 16-byte LDS-DMA pieces); every other stride-1
+ * shape is served by kmsr_conv3x3_wino_fwd_f32.  One persistent 8-wave workgroup per CU walks a contiguous range of
+ * (image, cout group, 4x64-pixel tile) items as ONE chunk stream (LDS-DMA rings for the pre-transformed weights and the raw input
+ * rows, one barrier per 8-channel chunk).  MFMA tile v_mfma_f32_16x16x4_f32 with all 16 transform points of a (channel, tile) pair
+ * in one lane: each lane computes its own B operand (the 4x4 input transform of its patch) from the raw rows in LDS, and the
+ * output transform is lane-local -- the transformed inputs never go through LDS and the epilogue needs no exchange.
+ * Packed layout [ceil(Cout/64)][ceil(Cin/8)][2 steps][4 channel blocks of 16][4][64 lanes][4].  Cout <= 1024 when bias is given
+ * (the bias vector is staged in LDS). */
 size_t kmsr_conv3x3_winov_packed_weight_floats(int32_t Cin, int32_t Cout);
 int kmsr_conv3x3_winov_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int32_t Cin, int32_t Cout, float* packed,
                                         void* stream);

@@ -75,9 +75,6 @@ SYMBOLS = {
     "kmsr_patch_nan_counts_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "kmsr_gather_patches_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "kmsr_nlm_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
-    "kmsr_conv3x3_winod_packed_weight_floats": (_sz, [_i32, _i32]),
-    "kmsr_conv3x3_winod_pack_weights_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
-    "kmsr_conv3x3_winod_fwd_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "kmsr_conv3x3_winov_packed_weight_floats": (_sz, [_i32, _i32]),
     "kmsr_conv3x3_winov_pack_weights_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "kmsr_conv3x3_winov_fwd_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -42,10 +42,8 @@ constexpr int TROWS = 2, TCOLS = 32;   // tiles per workgroup: 2 x 32  (output 4
 constexpr int kThreads = 512;
 constexpr int VUF = 16 * VCK * VCO;    // 8192 floats = 32 KB of U per chunk: [step 2][cb16 4][m 4][lane 64][jj 4]
 constexpr int NU = 3;                  // U ring slots (chunk G+2 is requested during chunk G)
-constexpr int DMA_WAVES = 8;                       // every wave issues its share of the DMA (concentrating it on one wave per SIMD was slower: 439 vs 394 us)
-                                                   // partner (wave + 4) keeps the matrix pipe to itself, so the ~130 cycles an LDS-DMA
-                                                   // instruction costs its issuer are not lost (both partners issuing at once: -47 us)
-constexpr int UINSTR = VUF / 256 / DMA_WAVES;      // 8 U DMA instructions per issuing wave and chunk
+constexpr int UINSTR = VUF / 4 / kThreads;         // 4 U DMA instructions per wave and chunk (every wave issues its share: concentrating
+                                                   // the DMA on one wave per SIMD was slower, 439 vs 394 us)
 constexpr int RROWS = 2 * TROWS + 2;   // 6 input rows
 constexpr int RQ = (2 * TCOLS + 8) / 4;            // 18 float4 per row segment: columns tx0-4 .. tx0+67
 constexpr int RCOLS = 4 * RQ;                      // 72
@@ -135,27 +133,23 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
     if (it0 >= it1) return;                                  // block-uniform
     const int T = (it1 - it0) * nch;                         // chunks in this workgroup's stream
 
-    const bool dma_wave = wv < DMA_WAVES;                    // wave-uniform
     const float* zero_page = g_zero_page;
     asm volatile("" : "+s"(zero_page));                      // resolved once (the GOT load would otherwise be repeated per chunk)
 
     // ---- DMA cursors.  U: chunk gU of the stream = chunk cU of item itU (only its cout group matters).
     int gU = 0, cU = 0, itU = it0, cgU = (it0 / p.tiles) % p.cgs;
-    const float* usrc = zero_page;                           // source of the chunk being issued (set by part 0)
-    int ustride = 0;
+    const int uoff = (UINSTR * wv * 64 + lane) * 4;          // this lane's float offset inside a chunk of U (instruction i: + 256 i)
     auto issue_u = [&](int i0, int i1) {                     // DMA instructions [i0, i1) of chunk gU; the cursor advances after the last one
         float* ub = lds + OFF_U + (gU % NU) * VUF;
-        if (i0 == 0) {
-            usrc = zero_page;
-            if (gU < T) usrc = wpk + ((long long)cgU * nch + cU) * VUF + (UINSTR * wv * 64 + lane) * 4;   // block-uniform branch
-            ustride = gU < T ? 256 : 0;
-        }
+        // wave-uniform base + constant lane offset (global_load_lds saddr form: no per-instruction address VALU).  Past the end of
+        // the stream the cursor stays on the last chunk: the slot is free, the re-fetched data is never read.
+        const float* __restrict__ ubase = wpk + ((long long)cgU * nch + cU) * VUF;
 #pragma unroll
         for (int i = i0; i < i1; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(usrc + i * ustride), (lds_void_t*)(ub + (UINSTR * wv + i) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(ubase + uoff + i * 256), (lds_void_t*)(ub + (UINSTR * wv + i) * 256), 16, 0, 0);
         if (i1 == UINSTR) {
             ++gU;
-            if (++cU == nch) {
+            if (gU < T && ++cU == nch) {
                 cU = 0;
                 ++itU;
                 cgU = (itU / p.tiles) % p.cgs;
@@ -164,29 +158,35 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
     };
     // raw rows: chunk gR = chunk cR of item itR.  Raw tile, lane-linear: L = (2 wv + i) * 64 + lane <-> (segment = L / 18 =
     // channel * 6 + row, q = L % 18 = float4 within the row); LDS offset = 4 L floats; instruction slots 14, 15 go to the dump.
-    int gR = 0, cR = 0, itR = it0, tyR = 0, txR = 0;
+    int gR = 0, cR = 0, itR = it0;
+    int roff[RINSTR];                                        // per-lane float offset of its 16-byte piece inside an 8-channel chunk, -1: padding
     const float* xnR = xg;
-    auto raw_item = [&]() {                                  // scalars of item itR (when the cursor enters a new item)
+    auto raw_map = [&]() {                                   // lane map of item itR (when the cursor enters a new item)
         const int tile = itR % p.tiles, n = itR / (p.tiles * p.cgs);
-        tyR = (tile / p.tiles_x) * (2 * TROWS);
-        txR = (tile % p.tiles_x) * (2 * TCOLS);
+        const int ty0 = (tile / p.tiles_x) * (2 * TROWS), tx0 = (tile % p.tiles_x) * (2 * TCOLS);
         xnR = xg + (long long)n * p.Cin * HW;
-    };
-    raw_item();
-    auto issue_raw = [&]() {
-        const float* __restrict__ xc = xnR + (long long)cR * VCK * HW;
-        const int cin_left = gR < T ? p.Cin - cR * VCK : 0;  // past the end of the stream: zeros
-        float* rb = lds + OFF_R + (gR % NRAW) * RAWF;
         int lane_o = lane;
-        asm volatile("" : "+v"(lane_o));                     // compute the lane map HERE, per chunk (only the issuing waves pay for it, in
-                                                             // the shadow of their SIMD partners; kept in registers it would be spilled)
+        asm volatile("" : "+v"(lane_o));                     // recompute HERE (hoisted out of the stream loop the lane constants would be spilled)
 #pragma unroll
         for (int i = 0; i < RINSTR; ++i) {
             const int L = (RINSTR * wv + i) * 64 + lane_o;
             const int seg = L / RQ, q = L - seg * RQ, ch = seg / RROWS, row = seg - ch * RROWS;
-            const int gy = tyR - 1 + row, gx = txR - 4 + 4 * q;
-            const bool ok = L < RLANES && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W && ch < cin_left;
-            const float* src = ok ? xc + (ch * HW + (long long)gy * W + gx) : zero_page;
+            const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * q;
+            const bool ok = L < RLANES && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+            roff[i] = ok ? (int)(ch * HW + (long long)gy * W + gx) : -1;
+        }
+    };
+    raw_map();
+    auto issue_raw = [&]() {
+        const float* __restrict__ xc = xnR + (long long)cR * VCK * HW;
+        const int cin_left = gR < T ? p.Cin - cR * VCK : 0;  // past the end of the stream: zeros
+        float* rb = lds + OFF_R + (gR % NRAW) * RAWF;
+        const bool tail = cin_left < VCK;                    // block-uniform: only a channel-tail chunk (or the end of the stream) needs the channel test
+#pragma unroll
+        for (int i = 0; i < RINSTR; ++i) {
+            bool ok = roff[i] >= 0;
+            if (tail) ok = ok && ((RINSTR * wv + i) * 64 + lane) / (RQ * RROWS) < cin_left;
+            const float* src = ok ? xc + roff[i] : zero_page;
             const int slot = RINSTR * wv + i;                // wave-uniform
             float* dst = slot < RREAL ? rb + slot * 256 : lds + OFF_DUMP;
             __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
         if (++cR == nch) {
             cR = 0;
             ++itR;
-            if (gR < T) raw_item();
+            if (gR < T) raw_map();
         }
     };
 
@@ -210,20 +210,22 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
         for (int r = 0; r < 4; ++r) q.p[r] = *reinterpret_cast<const f32x2*>(rp + r * RCOLS);
         return q;
     };
-    // row transform of one patch column: tt[i][c] = (B^T d)[i][c] from the column's four values d0 .. d3
-    auto rows_col = [&](f32x4 (&tt)[4], int c, float d0, float d1, float d2, float d3) {
-        tt[0][c] = d0 - d2;
-        tt[1][c] = d1 + d2;
-        tt[2][c] = d2 - d1;
-        tt[3][c] = d1 - d3;
+    // row transform of one patch column c: t[i][c] = (B^T d)[i][c] from the column's four values d0 .. d3 (4 VALU)
+    auto rows_col = [&](float (&t)[4][4], int c, float d0, float d1, float d2, float d3) {
+        t[0][c] = d0 - d2;
+        t[1][c] = d1 + d2;
+        t[2][c] = d2 - d1;
+        t[3][c] = d1 - d3;
+        asm volatile("" : "+v"(t[0][c]), "+v"(t[1][c]), "+v"(t[2][c]), "+v"(t[3][c]));   // keep the VALU work where it is written (LLVM would sink it)
     };
-    auto cols_of = [&](const f32x4 (&tt)[4], float (&v)[16], int i0, int i1) {  // v[4i + j] = (t B)[i][j] for i in [i0, i1)
+    auto cols_of = [&](const float (&t)[4][4], float (&v)[16]) {               // v[4i + j] = (t B)[i][j]  (16 VALU)
 #pragma unroll
-        for (int i = i0; i < i1; ++i) {
-            v[4 * i + 0] = tt[i][0] - tt[i][2];
-            v[4 * i + 1] = tt[i][1] + tt[i][2];
-            v[4 * i + 2] = tt[i][2] - tt[i][1];
-            v[4 * i + 3] = tt[i][1] - tt[i][3];
+        for (int i = 0; i < 4; ++i) {
+            v[4 * i + 0] = t[i][0] - t[i][2];
+            v[4 * i + 1] = t[i][1] + t[i][2];
+            v[4 * i + 2] = t[i][2] - t[i][1];
+            v[4 * i + 3] = t[i][1] - t[i][3];
+            asm volatile("" : "+v"(v[4 * i + 0]), "+v"(v[4 * i + 1]), "+v"(v[4 * i + 2]), "+v"(v[4 * i + 3]));
         }
     };
 
@@ -241,25 +243,23 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
     for (int i = tid; i < MAX_BIAS; i += kThreads) lds[OFF_B + i] = (bias && i < p.Cout) ? bias[i] : 0.f;
 
     // ---- prologue of the stream.  In flight, oldest first: raw(0) raw(1) U(0) raw(2) U(1) raw(3).
-    if (dma_wave) {
-        issue_raw();
-        issue_raw();
-        issue_u(0, UINSTR);
-        issue_raw();
-        issue_u(0, UINSTR);
-        issue_raw();
-    }
-    wait_dma<3 * RINSTR + 2 * UINSTR>();                     // raw(0) has landed (this wave's part; the other waves have nothing in flight)
+    issue_raw();
+    issue_raw();
+    issue_u(0, UINSTR);
+    issue_raw();
+    issue_u(0, UINSTR);
+    issue_raw();
+    wait_dma<3 * RINSTR + 2 * UINSTR>();                     // raw(0) has landed (this wave's part)
     barrier_lds();
     float vA[16], vB[16];
     {
         const PatchPair k0 = load_pair(0, 0, 0), k1 = load_pair(0, 0, 1), k2 = load_pair(0, 0, 2);
-        f32x4 tt[4];
+        float tt[4][4];
         rows_col(tt, 0, k0.p[0].y, k0.p[1].y, k0.p[2].y, k0.p[3].y);
         rows_col(tt, 1, k1.p[0].x, k1.p[1].x, k1.p[2].x, k1.p[3].x);
         rows_col(tt, 2, k1.p[0].y, k1.p[1].y, k1.p[2].y, k1.p[3].y);
         rows_col(tt, 3, k2.p[0].x, k2.p[1].x, k2.p[2].x, k2.p[3].x);
-        cols_of(tt, vA, 0, 4);
+        cols_of(tt, vA);
     }
     wait_dma<2 * RINSTR + UINSTR>();                         // raw(1), U(0) have landed
     barrier_lds();
@@ -273,12 +273,15 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
         acc[0][4 * (M) + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32((A0)[jj], (V)[4 * (M) + jj], acc[0][4 * (M) + jj], 0, 0, 0); \
         acc[1][4 * (M) + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32((A1)[jj], (V)[4 * (M) + jj], acc[1][4 * (M) + jj], 0, 0, 0); \
     }
-    // One step = 32 MFMAs on V(cur) with the NEXT step's V computed between them (hand-placed, pinned with sched_barrier):
-    //   group 0: request two column pairs of the next step's patch (8 ds_read_b64) and the A operands of group 1;   8 MFMAs
-    //   group 1: A operands of group 2;  8 MFMAs + row transform of patch columns 0, 1;  request the third column pair
-    //   group 2: A operands of group 3;  8 MFMAs + row transform of patch columns 2, 3
-    //   group 3: A operands of the next step's group 0;  8 MFMAs + column transform (16 VALU)
-    // (g, step) = this step; (pg, ps) = where the next step's patch lives; (ng, ns) = where the next step's A operands live.
+    // One step = 32 MFMAs on V(cur) plus the NEXT step's V.  On gfx950 the f32 MFMA and the VALU do NOT co-execute (both run on the
+    // vector FMA lanes: profiles/r02_ubench_f32_mfma_valu.log -- every VALU instruction adds ~4.5 cycles to the SIMD's MFMA period,
+    // every MFMA <-> VALU alternation ~11), so the VALU work is kept minimal and CLUSTERED, not interleaved; only the LDS requests
+    // (A operands one 8-MFMA group ahead, the patch one block ahead) are spread, pinned with sched_barrier:
+    //   request two column pairs of the next step's patch + A(group 1);  8 MFMAs;  request A(group 2);  8 MFMAs;
+    //   VALU block 1 (12): row transform of patch columns 0..2;  request the third column pair + A(group 3);  8 MFMAs;
+    //   [this chunk's DMA instructions];  request A(next step's group 0);
+    //   VALU block 2 (20): row transform of column 3, column transform;  8 MFMAs.
+    // (g, s) = this step; (pg, ps) = where the next step's patch lives; (ng, ns) = where the next step's A operands live.
     auto step = [&](int g, int s, const float (&vc)[16], float (&vn)[16], int pg, int ps, int ng, int ns, bool issue) {
         PatchPair k0 = load_pair(pg, ps, 0);
         const PatchPair k1 = load_pair(pg, ps, 1);
@@ -287,34 +290,33 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
         KMSR_SB();
         KMSR_MFMA8(0, a0[0], a1[0], vc);
         KMSR_SB();
-        if (issue && dma_wave) issue_u(0, UINSTR / 2);       // this chunk's 12 DMA instructions of an issuing wave, four per MFMA group
         a0[0] = *reinterpret_cast<const f32x4*>(a_ptr(g, s, 2));
         a1[0] = *reinterpret_cast<const f32x4*>(a_ptr(g, s, 2) + 4 * 256);
         KMSR_SB();
-        f32x4 tt[4];
         KMSR_MFMA8(1, a0[1], a1[1], vc);
+        KMSR_SB();
+        float tt[4][4];
         rows_col(tt, 0, k0.p[0].y, k0.p[1].y, k0.p[2].y, k0.p[3].y);
         rows_col(tt, 1, k1.p[0].x, k1.p[1].x, k1.p[2].x, k1.p[3].x);
-        asm volatile("" : "+v"(tt[0]), "+v"(tt[1]), "+v"(tt[2]), "+v"(tt[3]));     // keep the VALU work HERE (LLVM would sink it)
+        rows_col(tt, 2, k1.p[0].y, k1.p[1].y, k1.p[2].y, k1.p[3].y);
         KMSR_SB();
         k0 = load_pair(pg, ps, 2);                           // third column pair into the first one's registers
-        if (issue && dma_wave) issue_u(UINSTR / 2, UINSTR);
         a0[1] = *reinterpret_cast<const f32x4*>(a_ptr(g, s, 3));
         a1[1] = *reinterpret_cast<const f32x4*>(a_ptr(g, s, 3) + 4 * 256);
         KMSR_SB();
         KMSR_MFMA8(2, a0[0], a1[0], vc);
-        rows_col(tt, 2, k1.p[0].y, k1.p[1].y, k1.p[2].y, k1.p[3].y);
-        rows_col(tt, 3, k0.p[0].x, k0.p[1].x, k0.p[2].x, k0.p[3].x);
-        asm volatile("" : "+v"(tt[0]), "+v"(tt[1]), "+v"(tt[2]), "+v"(tt[3]));
         KMSR_SB();
-        if (issue && dma_wave) issue_raw();
+        if (issue) {                                         // (compile-time after inlining) this chunk's 6 DMA instructions
+            issue_u(0, UINSTR);
+            issue_raw();
+        }
         a0[0] = *reinterpret_cast<const f32x4*>(a_ptr(ng, ns, 0));
         a1[0] = *reinterpret_cast<const f32x4*>(a_ptr(ng, ns, 0) + 4 * 256);
         KMSR_SB();
+        rows_col(tt, 3, k0.p[0].x, k0.p[1].x, k0.p[2].x, k0.p[3].x);
+        cols_of(tt, vn);
+        KMSR_SB();
         KMSR_MFMA8(3, a0[1], a1[1], vc);
-        cols_of(tt, vn, 0, 4);
-#pragma unroll
-        for (int x = 0; x < 16; ++x) asm volatile("" : "+v"(vn[x]));
         KMSR_SB();
     };
 
@@ -459,6 +461,7 @@ extern "C" int kmsr_conv3x3_winov_fwd_f32(const kmsr_conv3x3_desc* d, const floa
     if (d->pixel_shuffle && (d->Cout % 4)) return fail(KMSR_E_SHAPE, "pixel_shuffle needs Cout %% 4 == 0 (Cout=%d)", d->Cout);
     if (d->pixel_shuffle && residual) return fail(KMSR_E_BADARG, "residual is not supported together with pixel_shuffle");
     if (!x || !packed_w || !out) return fail(KMSR_E_BADARG, "null tensor pointer");
+    if (bias && d->Cout > MAX_BIAS) return fail(KMSR_E_UNSUPPORTED, "winograd-vreg conv stages the bias vector in LDS: Cout <= %d (Cout=%d)", MAX_BIAS, d->Cout);
     if ((long long)d->H * d->W * VCK >= (1ll << 31)) return fail(KMSR_E_UNSUPPORTED, "image plane exceeds 2^28 elements");
     WinoVParams p{};
     p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout;

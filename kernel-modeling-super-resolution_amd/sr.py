@@ -45,18 +45,6 @@ def pack_conv3x3_weight_wino(weight):
     return packed
 
 
-def pack_conv3x3_weight_wino_dma(weight):
-    """[Cout,Cin,3,3] -> G g G^T packed in 8-channel chunks for conv3x3(..., algo="winograd_dma")."""
-    lib = L.load()
-    assert weight.is_cuda and weight.dtype == torch.float32 and weight.ndim == 4 and weight.shape[2:] == (3, 3)
-    w = weight.detach().contiguous()
-    Cout, Cin = w.shape[0], w.shape[1]
-    packed = torch.empty(lib.kmsr_conv3x3_winod_packed_weight_floats(Cin, Cout), device=w.device, dtype=torch.float32)
-    with torch.cuda.device(w.device):
-        L.check(lib.kmsr_conv3x3_winod_pack_weights_f32(L.ptr(w), Cin, Cout, L.ptr(packed), L.current_stream()))
-    return packed
-
-
 def pack_conv3x3_weight_wino_vreg(weight):
     """[Cout,Cin,3,3] -> G g G^T packed for conv3x3(..., algo="winograd_vreg") (a lane's four transform columns adjacent)."""
     lib = L.load()
@@ -76,40 +64,39 @@ def winograd_eligible(cin, cout, stride=1, width=2):
 
 
 def pick_algo(cin, cout, stride, width, use_winograd=True):
-    """Kernel for a stride-1 3x3 conv of this shape: the LDS-DMA Winograd variant when rows are 16-byte aligned
-    (W % 4 == 0), the register-staged Winograd kernel for other even widths, the direct MFMA / VALU kernels otherwise."""
+    """Kernel for a stride-1 3x3 conv of this shape: the persistent LDS-DMA Winograd kernel when rows are 16-byte aligned
+    (W % 4 == 0) and the bias vector fits its LDS staging (Cout <= 1024), the register-staged Winograd kernel for other even
+    widths, the direct MFMA / VALU kernels otherwise."""
     if not (use_winograd and winograd_eligible(cin, cout, stride, width)):
         return "direct"
-    return "winograd_dma" if width % 4 == 0 else "winograd"
+    return "winograd_vreg" if width % 4 == 0 and cout <= 1024 else "winograd"
 
 
 def pack_for(algo, weight):
     return {"direct": pack_conv3x3_weight, "winograd": pack_conv3x3_weight_wino,
-            "winograd_dma": pack_conv3x3_weight_wino_dma, "winograd_vreg": pack_conv3x3_weight_wino_vreg}[algo](weight)
+            "winograd_vreg": pack_conv3x3_weight_wino_vreg}[algo](weight)
 
 
 def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuffle=False, stride=1, out=None,
             algo="direct"):
     """out = epilogue(conv3x3(x, w)) with zero padding 1 (semantics: include/kmsr.h).  x [N,Cin,H,W] float32 CUDA.
-    algo="direct": packed_w from pack_conv3x3_weight; "winograd" / "winograd_dma": from pack_conv3x3_weight_wino[_dma]
+    algo="direct": packed_w from pack_conv3x3_weight; "winograd" / "winograd_vreg": from pack_conv3x3_weight_wino[_vreg]
     (pick_algo / pack_for choose and pack for a shape)."""
     lib = L.load()
     if not (x.is_cuda and x.dtype == torch.float32 and x.ndim == 4):
         raise ValueError("x must be a 4-D float32 CUDA tensor")
     x = x.contiguous()
-    if algo in ("winograd_dma", "winograd_vreg") and x.data_ptr() % 16:
+    if algo == "winograd_vreg" and x.data_ptr() % 16:
         x = x.clone()                    # a view at an odd storage offset: the LDS-DMA kernel fetches 16-byte pieces
     N, Cin, H, W = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     d = L.Conv3x3Desc()
     d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, Cin, H, W, int(cout), int(stride)
     d.relu, d.pixel_shuffle = int(bool(relu)), int(bool(pixel_shuffle))
-    d.flags = int(__import__("os").environ.get("KMSR_EXP_FLAGS", "0"), 0)
-    wino = algo in ("winograd", "winograd_dma", "winograd_vreg")
+    wino = algo in ("winograd", "winograd_vreg")
     if wino and stride != 1:
         raise NotImplementedError("winograd conv needs stride 1")
     need = {"direct": lib.kmsr_conv3x3_packed_weight_floats, "winograd": lib.kmsr_conv3x3_wino_packed_weight_floats,
-            "winograd_dma": lib.kmsr_conv3x3_winod_packed_weight_floats,
             "winograd_vreg": lib.kmsr_conv3x3_winov_packed_weight_floats}[algo](Cin, int(cout))
     assert packed_w.is_cuda and packed_w.dtype == torch.float32 and packed_w.numel() == need, \
         f"packed weight has {packed_w.numel()} floats, conv {Cin}->{cout} needs {need}"
@@ -124,11 +111,9 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     if residual is not None:
         residual = residual.contiguous()
         assert tuple(residual.shape) == oshape and residual.is_cuda
-        if algo == "winograd_vreg" and residual.data_ptr() % 16:
-            residual = residual.clone()  # the skip tensor is staged by 16-byte LDS-DMA pieces as well
     with torch.cuda.device(x.device):
         fwd = {"direct": lib.kmsr_conv3x3_fwd_f32, "winograd": lib.kmsr_conv3x3_wino_fwd_f32,
-               "winograd_dma": lib.kmsr_conv3x3_winod_fwd_f32, "winograd_vreg": lib.kmsr_conv3x3_winov_fwd_f32}[algo]
+               "winograd_vreg": lib.kmsr_conv3x3_winov_fwd_f32}[algo]
         L.check(fwd(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out), L.current_stream()))
     return out
 
@@ -398,7 +383,8 @@ class SRNet(nn.Module):
         self.tail = nn.Conv2d(n_feats, n_colors, 3, padding=1)
         self._caches = {}
         self.use_winograd = True    # inference path: Winograd F(2x2,3x3) MFMA kernel for the F->F / F->4F convs
-        self.fuse_upsampler = False  # inference path, x4 only: collapse up1/PS/up2/PS/tail into one 5x5 conv + PS4 (opt-in)
+        self.fuse_upsampler = True   # inference path, x4 only: up1/PS/up2/PS/tail (linear) run as one 5x5 conv + PS4 + exact frame strips
+        #                              (same outputs, tests/test_fullsize_gpu.py; False = three conv3x3 launches)
         self._fused_up = _FusedUpsampler()
 
     def _packed(self, name, conv, algo="direct"):

@@ -158,8 +158,8 @@ def test_compose_upsampler_is_the_interior_operator():
 def test_pick_algo_dispatch():
     """Host-side kernel choice for a stride-1 3x3 conv (kmsr_amd/sr.py: pick_algo)."""
     from kmsr_amd.sr import pick_algo
-    assert pick_algo(64, 64, 1, 256) == "winograd_dma"          # rows 16-byte aligned -> LDS-DMA staged Winograd
-    assert pick_algo(64, 256, 1, 512) == "winograd_dma"
+    assert pick_algo(64, 64, 1, 256) == "winograd_vreg"         # rows 16-byte aligned -> persistent LDS-DMA Winograd kernel
+    assert pick_algo(64, 256, 1, 512) == "winograd_vreg"
     assert pick_algo(64, 64, 1, 70) == "winograd"               # even width only -> register-staged Winograd
     assert pick_algo(64, 64, 1, 71) == "direct"                 # odd width
     assert pick_algo(3, 64, 1, 256) == "direct"                 # head: too few input channels
