@@ -256,6 +256,24 @@ class DegradeSRWorkload:
                 "kernel_ms": round(kernel_ms, 4), "launches_timed": len(ms),
                 "what": "HIP events around the kmsr_degrade_f32 call of every instrumented step (tap table already built)"}
 
+    def roofline_degrade_northstar(self, launches=20):
+        """The same fused kernel on north_star's unit of the degradation path (HR [32,5,1024,1024] ->
+        LR [32,5,256,256], 713 MB per launch), measured live after the timed region: the config-2 batch above has only 48 planes
+        (201 MB, ~65 us per launch), too little work to fill 256 CUs for long."""
+        wl = DegradeWorkload(self.hr.device, 0)
+        for _ in range(3):
+            wl.step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            wl.step()
+        e1.record()
+        torch.cuda.synchronize()
+        out = wl.roofline(e0.elapsed_time(e1) / launches)
+        out["what"] = f"{launches} back-to-back launches on HR [32,5,1024,1024] (tap table built once), HIP events on the launch stream"
+        del wl
+        return out
+
     def cpu_baseline(self, budget_s=10.0):
         """Same step on the host cores: oracle degradation (C restatement, OpenMP) + the stock-torch SR oracle module
         (ATen CPU convs -- the way the reference itself runs its conv stacks on a CPU), 1 patch at a time; at all cores
@@ -529,6 +547,7 @@ def main():
         }
         if hasattr(wl, "roofline_degrade"):
             out["roofline_degrade"] = wl.roofline_degrade()
+            out["roofline_degrade_northstar"] = wl.roofline_degrade_northstar()
         if instrumented is not None:
             out["instrumented_ms_per_step"] = instrumented
         if args.workload == "degrade_sr":

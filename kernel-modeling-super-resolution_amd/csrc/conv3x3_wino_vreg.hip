@@ -14,7 +14,7 @@
 //   * all 16 transform points of a (channel, tile) pair sit in one lane, so the output transform A^T M A is lane-local:
 //     no exchange through LDS, no epilogue barrier -- the epilogue is ~200 VALU and the stores;
 //   * the workgroup (8 waves = 2 channel halves x 4 tile quarters = 64 channels x 64 tiles, one per CU) is PERSISTENT: it walks
-//     a contiguous range of (image, cout group, tile) items and treats their chunks as ONE stream.  U (pre-transformed weights,
+//     an interleaved list of (image, cout group, tile) items and treats their chunks as ONE stream.  U (pre-transformed weights,
 //     32 KB per 8-channel chunk, shared by the 8 waves) and the raw input rows (13.5 KB per chunk) arrive by LDS-DMA in rings
 //     of 3 and 4 slots; the DMA for chunk G+2 / G+4 is issued during chunk G whatever item it belongs to, so only the first
 //     item of a workgroup sees a cold prologue;
@@ -125,13 +125,15 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
     const int H = p.H, W = p.W, nch = p.nchunks;
     const long long HW = (long long)H * W;
 
-    // contiguous item range of this workgroup; workgroups that share an XCD (id % 8) get neighbouring ranges
+    // Items of this workgroup: vb, vb + nwg, vb + 2 nwg, ...  (vb = XCD-grouped id: the workgroups of one XCD hold consecutive vb).
+    // All workgroups walk their streams in step, so at any moment the chip works on ~nwg CONSECUTIVE items: horizontally and
+    // vertically adjacent tiles (shared halo rows / columns) and the common U chunk are touched at the same time by CUs of one
+    // XCD and are served from its L2 (contiguous per-workgroup ranges re-read them 4 items apart: 2.7x the algorithmic HBM bytes).
     const int nwg = gridDim.x, bq = nwg >> 3, br = nwg & 7, xcd = blockIdx.x & 7;
     const int vb = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (blockIdx.x >> 3);
-    const int per = (p.n_items + nwg - 1) / nwg;
-    const int it0 = vb * per, it1 = min(it0 + per, p.n_items);
-    if (it0 >= it1) return;                                  // block-uniform
-    const int T = (it1 - it0) * nch;                         // chunks in this workgroup's stream
+    const int it0 = vb, istep = nwg;
+    if (it0 >= p.n_items) return;                            // block-uniform
+    const int T = ((p.n_items - it0 + istep - 1) / istep) * nch;   // chunks in this workgroup's stream
 
     const float* zero_page = g_zero_page;
     asm volatile("" : "+s"(zero_page));                      // resolved once (the GOT load would otherwise be repeated per chunk)
@@ -151,7 +153,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
             ++gU;
             if (gU < T && ++cU == nch) {
                 cU = 0;
-                ++itU;
+                itU += istep;
                 cgU = (itU / p.tiles) % p.cgs;
             }
         }
@@ -194,7 +196,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
         ++gR;
         if (++cR == nch) {
             cR = 0;
-            ++itR;
+            itR += istep;
             if (gR < T) raw_map();
         }
     };
@@ -421,7 +423,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
             store_outputs(ip, 0, Y0, rr0);
             outputs_of(ip, 1, Y1);
             store_outputs(ip, 1, Y1, rr1);
-            ++item;
+            item += istep;
         }
     }
 #undef KMSR_MFMA8

@@ -159,9 +159,16 @@ __global__ void __launch_bounds__(BTHREADS) degrade_bwd_kernel(BwdParams pr) {
 constexpr int VB_F = 4, VB_K = 13, VB_ROWS = (BT - 1) * VB_F + VB_K, VB_PITCH = VB_ROWS;   // 73 (odd)
 constexpr int VB_S = 8, VB_TAPS = VB_K * VB_K;
 constexpr int VB_XS = VB_ROWS * VB_PITCH + 8;      // + slack: the 19th sample of the v mod 4 > 0 threads is read, not used
+// ALIGNED tile fill (W % 4 == 0, 16-byte aligned rows, zero padding): the 73-column window starts at HR column 4 j0 - 6, so the
+// aligned window [4 j0 - 8, 4 j0 + 72) = 20 float4 per row covers it with every float4 wholly inside or outside the image:
+// 3 global_load_dwordx4 + 3 ds_write_b128 per thread instead of 11 dword loads / stores with per-element index arithmetic
+// (the fill, not HBM, bounded the scalar version: 0.19 of the HBM peak).  LDS pitch 84 floats (16-byte rows; 84 = 20 mod 32 keeps
+// the 13 tap rows a wave touches on different banks except u, u + 8).
+constexpr int VB_AQ = 20, VB_APITCH = 84, VB_AOFF = 2, VB_AXS = VB_ROWS * VB_APITCH;
 
+template <bool ALIGNED>
 __global__ void __launch_bounds__(BTHREADS) degrade_bwd_vb_kernel(BwdParams p) {
-    __shared__ __attribute__((aligned(16))) float xs[VB_XS];
+    __shared__ __attribute__((aligned(16))) float xs[ALIGNED ? VB_AXS : VB_XS];
     __shared__ __attribute__((aligned(16))) float gs[BT * BT];
     __shared__ float red[VB_S * VB_TAPS + 64];
     const int tid = threadIdx.x;
@@ -171,23 +178,6 @@ __global__ void __launch_bounds__(BTHREADS) degrade_bwd_vb_kernel(BwdParams p) {
     const float* __restrict__ x = p.hr + n * p.sN + c * p.sC;
     const int y0 = i0 * VB_F - VB_K / 2, x0 = j0 * VB_F - VB_K / 2;
 
-    constexpr int NE = VB_ROWS * VB_ROWS, NT = (NE + BTHREADS - 1) / BTHREADS;
-    float v[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {              // all loads in flight before the first LDS store
-        const int e = tid + t * BTHREADS;
-        const int r = e / VB_ROWS, q = e - r * VB_ROWS;
-        int gy = y0 + r, gx = x0 + q;
-        if (p.pad_zero) {
-            const bool ok = e < NE && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            const float tv = x[ok ? gy * p.sH + gx : 0];
-            v[t] = ok ? tv : 0.f;
-        } else {
-            gy = min(max(gy, 0), p.H - 1);
-            gx = min(max(gx, 0), p.W - 1);
-            v[t] = x[gy * p.sH + gx];
-        }
-    }
     const float* __restrict__ gp = p.g + (long long)plane * p.h * p.w;
     float gv = 0.f;
     if (tid < BT * BT) {
@@ -196,13 +186,50 @@ __global__ void __launch_bounds__(BTHREADS) degrade_bwd_vb_kernel(BwdParams p) {
         const float t = gp[ok ? (long long)i * p.w + j : 0];
         gv = ok ? t : 0.f;
     }
+    if constexpr (ALIGNED) {
+        constexpr int NE4 = VB_ROWS * VB_AQ, NT4 = (NE4 + BTHREADS - 1) / BTHREADS;
+        f32x4 v4[NT4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int e = tid + t * BTHREADS;
-        if (e < NE) xs[e] = v[t];               // pitch == row length: the tile is stored densely
+        for (int t = 0; t < NT4; ++t) {         // all loads in flight before the first LDS store
+            const int e = tid + t * BTHREADS;
+            const int r = e / VB_AQ, q = e - r * VB_AQ;
+            const int gy = y0 + r, gx = x0 - VB_AOFF + 4 * q;
+            const bool ok = e < NE4 && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+            const f32x4 tv = *reinterpret_cast<const f32x4*>(x + (ok ? gy * p.sH + gx : 0));
+            v4[t] = ok ? tv : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int t = 0; t < NT4; ++t) {
+            const int e = tid + t * BTHREADS;
+            const int r = e / VB_AQ, q = e - r * VB_AQ;
+            if (e < NE4) *reinterpret_cast<f32x4*>(xs + r * VB_APITCH + 4 * q) = v4[t];
+        }
+    } else {
+        constexpr int NE = VB_ROWS * VB_ROWS, NT = (NE + BTHREADS - 1) / BTHREADS;
+        float v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {              // all loads in flight before the first LDS store
+            const int e = tid + t * BTHREADS;
+            const int r = e / VB_ROWS, q = e - r * VB_ROWS;
+            int gy = y0 + r, gx = x0 + q;
+            if (p.pad_zero) {
+                const bool ok = e < NE && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                const float tv = x[ok ? gy * p.sH + gx : 0];
+                v[t] = ok ? tv : 0.f;
+            } else {
+                gy = min(max(gy, 0), p.H - 1);
+                gx = min(max(gx, 0), p.W - 1);
+                v[t] = x[gy * p.sH + gx];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int e = tid + t * BTHREADS;
+            if (e < NE) xs[e] = v[t];               // pitch == row length: the tile is stored densely
+        }
+        if (tid < 8) xs[NE + tid] = 0.f;
     }
     if (tid < BT * BT) gs[tid] = gv;
-    if (tid < 8) xs[NE + tid] = 0.f;
     __syncthreads();
 
     const int vm = tid & 3, u = (tid >> 2) % VB_K, s = tid / (4 * VB_K);
@@ -211,7 +238,7 @@ __global__ void __launch_bounds__(BTHREADS) degrade_bwd_vb_kernel(BwdParams p) {
 #pragma unroll
         for (int rr = 0; rr < BT / VB_S; ++rr) {
             const int i = s + rr * VB_S;
-            const float* xr = xs + (i * VB_F + u) * VB_PITCH + vm;
+            const float* xr = xs + (i * VB_F + u) * (ALIGNED ? VB_APITCH : VB_PITCH) + (ALIGNED ? VB_AOFF : 0) + vm;
             float xv[BT + 3];
 #pragma unroll
             for (int j = 0; j < BT + 3; ++j) xv[j] = xr[VB_F * j];
@@ -343,7 +370,10 @@ extern "C" int kmsr_degrade_bwd_f32(const kmsr_degrade_desc* d, const float* hr,
     if (nblocks > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "grid too large");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (p.F == VB_F && p.kh == VB_K && p.kw == VB_K) {
-        degrade_bwd_vb_kernel<<<(int)nblocks, BTHREADS, 0, stream>>>(p);
+        const bool aligned = p.pad_zero && d->W % 4 == 0 && p.sH % 4 == 0 && p.sC % 4 == 0 && p.sN % 4 == 0 &&
+                             reinterpret_cast<uintptr_t>(hr) % 16 == 0;
+        if (aligned) degrade_bwd_vb_kernel<true><<<(int)nblocks, BTHREADS, 0, stream>>>(p);
+        else degrade_bwd_vb_kernel<false><<<(int)nblocks, BTHREADS, 0, stream>>>(p);
     } else {
         if (lds > 64 * 1024)
             KMSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(degrade_bwd_kernel<0, 0>),

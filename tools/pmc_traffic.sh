@@ -25,7 +25,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             agg[r['Kernel_Name'][:120]].append(float(r['Counter_Value']))
     res["pmc"][c] = {k: {"n": len(v), "mean_kb": sum(v) / len(v)} for k, v in agg.items() if 'kmsr' in k}
 json.dump(res, open(f'{out}/summary.json', 'w'), indent=1)
-for s in res["stats"][:8]: print('STAT', s)
+for s in res["stats"][:10]: print('STAT', s)
 for c, d in res["pmc"].items():
     for k, v in d.items(): print('PMC', c, k[:70], v)
 PY
