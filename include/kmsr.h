@@ -257,10 +257,38 @@ int kmsr_conv5x5_ps4_fwd_f32(int32_t N, int32_t Cin, int32_t H, int32_t W, int32
  * every (sample, band) "unit" runs its own bias-free chain of k x k convs with F.pad(mode='reflect') per layer.
  *   out[u,co,y,x] = sum_{ci,a,b} w[u,ci,a*k+b,co] * x[u,ci,refl(y+a-k/2),refl(x+b-k/2)],  refl(-i) = i, refl(H-1+i) = H-1-i
  *   x [U,Cin,H,W], w [U][Cin][k*k][Cout] (already scaled / folded by the caller), out [U,Cout,H,W]
- *   k in {1,3,5,7}, Cin <= 32, Cout in {1, 32}; H, W > k/2.
+ *   k in {1,3,5,7}, Cin <= 64, Cout in {1, 5, 32, 64}; H, W > k/2.
  * ========================================================================================== */
 int kmsr_conv_reflect_f32(const float* x, const float* w, int32_t U, int32_t Cin, int32_t Cout, int32_t H, int32_t W,
                           int32_t k, float* out, void* stream);
+
+/* ============================================================================================
+ * The same small-channel k x k convolution as a family with gradient legs -- what the KernelGAN trainers
+ * (muti_kernel/train.py:234-323, single_kernel/train.py:250-347) differentiate through: the generators' reflect-padded
+ * chains (per-unit weights) and the PatchDiscriminator's zero-padded 7x7 / 1x1 convs (muti_kernel/networks.py:250-268,
+ * one shared weight set, bias).
+ *   fwd  : out[u,co,y,x] = bias[co] + sum_{ci,a,b} w[u|0,ci,a*k+b,co] * xpad[u,ci,y+a-k/2,x+b-k/2]
+ *          (xpad = reflect or zero extension of x by k/2); bias may be NULL.
+ *   dgrad: dx = (d out / d x)^T dy.  dy [U,Cout,H,W]; wT [U|1][Cout][k*k][Cin] = w with its channel axes exchanged
+ *          (taps NOT flipped -- the kernel walks them backwards); dx [U,Cin,H,W].  Reflect padding folds the gradient
+ *          of every mirrored position back onto the interior pixel it copies.
+ *   wgrad: dw[u|0,ci,a*k+b,co] = sum_{(u,)y,x} dy[u,co,y,x] * xpad[u,ci,y+a-k/2,x+b-k/2]  (summed over units when the
+ *          weights are shared); fixed-order reduction, run-to-run identical.  workspace from
+ *          kmsr_convk_wgrad_workspace_bytes(d) (0 = unsupported configuration).
+ *   k odd in 1..7, Cin, Cout <= 64; instantiated: fwd Cout in {1,5,32,64}, dgrad Cin in {1,5,32,64}, wgrad
+ *   Cin*k*k*Cout <= 2048 * (16 if Cout%16==0, 4 if Cout%4==0, else 1).  H, W > k/2.
+ * ========================================================================================== */
+enum { KMSR_CONVK_REFLECT = 0, KMSR_CONVK_ZERO = 1 };
+typedef struct kmsr_convk_desc {
+    int32_t U, Cin, Cout, H, W, k;
+    int32_t pad_mode;        /* KMSR_CONVK_*                                                     */
+    int32_t shared_weights;  /* 0: one weight set per unit; 1: one weight set for all units      */
+} kmsr_convk_desc;
+int kmsr_convk_fwd_f32(const kmsr_convk_desc* d, const float* x, const float* w, const float* bias, float* out, void* stream);
+int kmsr_convk_dgrad_f32(const kmsr_convk_desc* d, const float* dy, const float* wT, float* dx, void* stream);
+size_t kmsr_convk_wgrad_workspace_bytes(const kmsr_convk_desc* d);
+int kmsr_convk_wgrad_f32(const kmsr_convk_desc* d, const float* x, const float* dy, float* dw, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* ============================================================================================
  * bf16 3x3 convolution (BASELINE config 4: 7-band x4 SR on 1024x1024 LR tiles -- the HBM-bound large-tile path).

@@ -44,6 +44,16 @@ class Conv3x3Desc(C.Structure):
     ]
 
 
+class ConvKDesc(C.Structure):
+    """struct kmsr_convk_desc (include/kmsr.h)"""
+    _fields_ = [
+        ("U", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("k", C.c_int32),
+        ("pad_mode", C.c_int32), ("shared_weights", C.c_int32),
+    ]
+
+
+CONVK_REFLECT, CONVK_ZERO = 0, 1
+
 _lib = None
 
 # every symbol include/kmsr.h declares: (name, restype, argtypes)
@@ -82,6 +92,10 @@ SYMBOLS = {
     "kmsr_conv5x5_ps4_pack_weights_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "kmsr_conv5x5_ps4_fwd_f32": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "kmsr_conv_reflect_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "kmsr_convk_fwd_f32": (C.c_int, [C.POINTER(ConvKDesc), _vp, _vp, _vp, _vp, _vp]),
+    "kmsr_convk_dgrad_f32": (C.c_int, [C.POINTER(ConvKDesc), _vp, _vp, _vp, _vp]),
+    "kmsr_convk_wgrad_workspace_bytes": (_sz, [C.POINTER(ConvKDesc)]),
+    "kmsr_convk_wgrad_f32": (C.c_int, [C.POINTER(ConvKDesc), _vp, _vp, _vp, _vp, _sz, _vp]),
     "kmsr_compose_kernels_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
                                            _vp, _vp]),
 }

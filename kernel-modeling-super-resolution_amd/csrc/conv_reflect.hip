@@ -1,4 +1,5 @@
-// Small-channel k x k convolution with reflect padding and per-unit weights (semantics: include/kmsr.h).
+// Small-channel k x k convolution with reflect (or zero) padding and per-unit (or shared) weights -- forward leg
+// (semantics: include/kmsr.h; the data / weight gradient legs are in convk_bwd.hip).
 // One workgroup = one 16x16 output tile of one unit; the reflect-padded input tile of ALL input channels sits in LDS
 // (<= 32 x 22 x 22 floats), each thread owns one pixel and all COUT output channels; weights are wave-uniform
 // ([ci][tap][co] contiguous per unit) so they arrive through the scalar cache and feed v_fmac as SGPR operands.
@@ -14,10 +15,10 @@ __device__ __forceinline__ int reflect_idx(int v, int n) {
     return v >= n ? 2 * (n - 1) - v : v;
 }
 
-template <int KS, int COUT>
+template <int KS, int COUT, bool ZERO>
 __global__ void __launch_bounds__(256) conv_reflect_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           float* __restrict__ out, int Cin, int H, int W, int tiles_x,
-                                                           int tiles) {
+                                                           const float* __restrict__ bias, float* __restrict__ out, int Cin,
+                                                           int H, int W, int tiles_x, int tiles, long long wstride) {
     constexpr int P = KS / 2, IT = RT + KS - 1;
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [Cin][IT][IT]
     const int tid = threadIdx.x;
@@ -32,8 +33,14 @@ __global__ void __launch_bounds__(256) conv_reflect_kernel(const float* __restri
         for (int q = 0; q < 8; ++q) {
             const int e = min(e0 + tid + 256 * q, n_el - 1);
             const int c = e / (IT * IT), rem = e - c * (IT * IT), r = rem / IT, cc = rem - r * IT;
-            const int gy = reflect_idx(min(ty0 + r - P, H - 1 + P), H), gx = reflect_idx(min(tx0 + cc - P, W - 1 + P), W);
-            v[q] = xu[((long long)c * H + gy) * W + gx];
+            if constexpr (ZERO) {
+                const int gy = ty0 + r - P, gx = tx0 + cc - P;
+                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                v[q] = in ? xu[((long long)c * H + gy) * W + gx] : 0.f;
+            } else {
+                const int gy = reflect_idx(min(ty0 + r - P, H - 1 + P), H), gx = reflect_idx(min(tx0 + cc - P, W - 1 + P), W);
+                v[q] = xu[((long long)c * H + gy) * W + gx];
+            }
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -45,8 +52,8 @@ __global__ void __launch_bounds__(256) conv_reflect_kernel(const float* __restri
     const int py = tid / RT, px = tid % RT;
     float acc[COUT];
 #pragma unroll
-    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
-    const float* __restrict__ wu = w + (long long)u * Cin * KS * KS * COUT;    // wave-uniform
+    for (int o = 0; o < COUT; ++o) acc[o] = bias ? bias[o] : 0.f;
+    const float* __restrict__ wu = w + (long long)u * wstride;                 // wave-uniform
     for (int c = 0; c < Cin; ++c) {
         const float* tc = tile + c * IT * IT + py * IT + px;
 #pragma unroll
@@ -67,15 +74,40 @@ __global__ void __launch_bounds__(256) conv_reflect_kernel(const float* __restri
     }
 }
 
-template <int KS, int COUT>
-int launch(const float* x, const float* w, int U, int Cin, int H, int W, float* out, hipStream_t st) {
+template <int KS, int COUT, bool ZERO>
+int launch(const float* x, const float* w, const float* bias, int U, int Cin, int H, int W, bool shared, float* out,
+           hipStream_t st) {
     const int tiles_x = ceil_div(W, RT), tiles = tiles_x * ceil_div(H, RT);
     const size_t shmem = (size_t)Cin * (RT + KS - 1) * (RT + KS - 1) * sizeof(float);
     if (shmem > 64 * 1024)
-        KMSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_reflect_kernel<KS, COUT>),
+        KMSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_reflect_kernel<KS, COUT, ZERO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    conv_reflect_kernel<KS, COUT><<<U * tiles, 256, shmem, st>>>(x, w, out, Cin, H, W, tiles_x, tiles);
+    conv_reflect_kernel<KS, COUT, ZERO><<<U * tiles, 256, shmem, st>>>(x, w, bias, out, Cin, H, W, tiles_x, tiles,
+                                                                       shared ? 0ll : (long long)Cin * KS * KS * COUT);
     KMSR_HIP_CHECK(hipGetLastError());
+    return KMSR_OK;
+}
+
+int convk_forward(const kmsr_convk_desc* d, const float* x, const float* w, const float* bias, float* out, hipStream_t st) {
+    const int k = d->k, Cout = d->Cout;
+    const bool zero = d->pad_mode == KMSR_CONVK_ZERO, shared = d->shared_weights != 0;
+#define KMSR_CR(K_, C_)                                                                                         \
+    if (k == K_ && Cout == C_)                                                                                  \
+        return zero ? launch<K_, C_, true>(x, w, bias, d->U, d->Cin, d->H, d->W, shared, out, st)               \
+                    : launch<K_, C_, false>(x, w, bias, d->U, d->Cin, d->H, d->W, shared, out, st);
+    KMSR_CR(1, 1) KMSR_CR(1, 32) KMSR_CR(1, 64) KMSR_CR(3, 1) KMSR_CR(3, 32) KMSR_CR(5, 1) KMSR_CR(5, 32) KMSR_CR(7, 1)
+    KMSR_CR(7, 5) KMSR_CR(7, 32) KMSR_CR(7, 64)
+#undef KMSR_CR
+    return fail(KMSR_E_UNSUPPORTED, "convk: k=%d Cout=%d not instantiated (k in 1,3,5,7; Cout in 1,5,32,64)", k, Cout);
+}
+
+int check_desc(const kmsr_convk_desc* d, const char* who) {
+    if (!d) return fail(KMSR_E_BADARG, "%s: null descriptor", who);
+    if (d->U <= 0 || d->Cin <= 0 || d->Cin > 64 || d->Cout <= 0 || d->Cout > 64 || d->k < 1 || d->k > 7 || !(d->k & 1) ||
+        d->H <= d->k / 2 || d->W <= d->k / 2)
+        return fail(KMSR_E_BADARG, "%s: bad shape U=%d Cin=%d Cout=%d H=%d W=%d k=%d", who, d->U, d->Cin, d->Cout, d->H, d->W, d->k);
+    if (d->pad_mode != KMSR_CONVK_REFLECT && d->pad_mode != KMSR_CONVK_ZERO) return fail(KMSR_E_BADARG, "%s: bad pad_mode", who);
+    if ((long long)d->U * ceil_div(d->H, RT) * ceil_div(d->W, RT) > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "%s: grid too large", who);
     return KMSR_OK;
 }
 
@@ -87,11 +119,14 @@ using namespace kmsr;
 extern "C" int kmsr_conv_reflect_f32(const float* x, const float* w, int32_t U, int32_t Cin, int32_t Cout, int32_t H,
                                      int32_t W, int32_t k, float* out, void* stream) {
     if (!x || !w || !out) return fail(KMSR_E_BADARG, "conv_reflect: null pointer");
-    if (U <= 0 || Cin <= 0 || Cin > 32 || H <= k / 2 || W <= k / 2) return fail(KMSR_E_BADARG, "conv_reflect: bad shape");
-    if ((long long)U * ceil_div(H, RT) * ceil_div(W, RT) > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv_reflect: grid too large");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-#define KMSR_CR(K_, C_) if (k == K_ && Cout == C_) return launch<K_, C_>(x, w, U, Cin, H, W, out, st);
-    KMSR_CR(1, 1) KMSR_CR(1, 32) KMSR_CR(3, 1) KMSR_CR(3, 32) KMSR_CR(5, 1) KMSR_CR(5, 32) KMSR_CR(7, 1) KMSR_CR(7, 32)
-#undef KMSR_CR
-    return fail(KMSR_E_UNSUPPORTED, "conv_reflect: k=%d Cout=%d not instantiated (k in 1,3,5,7; Cout in 1,32)", k, Cout);
+    kmsr_convk_desc d{U, Cin, Cout, H, W, k, KMSR_CONVK_REFLECT, 0};
+    if (int rc = check_desc(&d, "conv_reflect")) return rc;
+    return convk_forward(&d, x, w, nullptr, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int kmsr_convk_fwd_f32(const kmsr_convk_desc* d, const float* x, const float* w, const float* bias, float* out,
+                                  void* stream) {
+    if (!x || !w || !out) return fail(KMSR_E_BADARG, "convk_fwd: null pointer");
+    if (int rc = check_desc(d, "convk_fwd")) return rc;
+    return convk_forward(d, x, w, bias, out, static_cast<hipStream_t>(stream));
 }

@@ -46,6 +46,10 @@ def rank_seed(base_seed, rank=None):
     return (int(base_seed) + int(rank) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
 
 
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

@@ -9,8 +9,12 @@ Mirrors, with identical class names, constructor arguments and parameter names (
 extract_effective_kernels is ONE launch of kmsr_compose_kernels_f32 (one workgroup per (sample, band)) instead of
 ~20 000 tiny F.conv2d calls per sample.  The generators' forward (reflect-padded 6-layer chain + 3 avg-pools) runs as
 three launches of kmsr_conv_reflect_f32 over all (sample, band) units: the three trailing 1x1 layers carry no padding,
-so they fold exactly into the 3x3 layer (7x7 1->32, 5x5 32->32, 3x3 32->1).  Inference-only (the GAN trainers that
-would need its backward are SURVEY 8f N1 "next").
+so they fold exactly into the 3x3 layer (7x7 1->32, 5x5 32->32, 3x3 32->1).
+
+With autograd enabled the same three launches run through ConvKFunction (kmsr_convk_fwd / dgrad / wgrad_f32): the data
+gradient folds the reflect padding back, the weight gradient is per unit, and torch autograd finishes the chain rule
+through the (tiny) scale / fold einsums into the base weights and the condition encoder -- the path the KernelGAN
+trainers differentiate (muti_kernel/train.py:266-286, single_kernel/train.py:272-308; train_kernelgan.py here).
 """
 import ctypes as C
 from typing import Optional, Sequence
@@ -20,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .sr import conv3x3, pack_conv3x3_weight
+from .sr import Conv3x3Function, conv3x3, pack_conv3x3_weight
 
 KS = (7, 5, 3, 1, 1, 1)
 
@@ -38,12 +42,94 @@ def conv_reflect(x, w, k, cout):
     return out
 
 
+def _convk_desc(U, Cin, Cout, H, W, k, pad, shared):
+    d = L.ConvKDesc()
+    d.U, d.Cin, d.Cout, d.H, d.W, d.k = int(U), int(Cin), int(Cout), int(H), int(W), int(k)
+    d.pad_mode = {"reflect": L.CONVK_REFLECT, "zero": L.CONVK_ZERO}[pad]
+    d.shared_weights = int(bool(shared))
+    return d
+
+
+def convk_forward(x, w, k, pad="reflect", bias=None):
+    """x [U,Cin,H,W]; w [U,Cin,k*k,Cout] (per unit) or [Cin,k*k,Cout] (shared) -> [U,Cout,H,W]  (kmsr_convk_fwd_f32)."""
+    lib = L.load()
+    x, w = x.contiguous(), w.contiguous()
+    U, Cin, H, W = x.shape
+    shared = w.ndim == 3
+    cout = w.shape[-1]
+    assert tuple(w.shape[-3:]) == (Cin, k * k, cout) and (shared or w.shape[0] == U), f"weights {tuple(w.shape)} for x {tuple(x.shape)}, k={k}"
+    if bias is not None:
+        bias = bias.contiguous()
+        assert bias.numel() == cout and shared
+    out = torch.empty((U, cout, H, W), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(lib.kmsr_convk_fwd_f32(_convk_desc(U, Cin, cout, H, W, k, pad, shared), L.ptr(x), L.ptr(w), L.ptr(bias),
+                                       L.ptr(out), L.current_stream()))
+    return out
+
+
+def convk_dgrad(dy, w, k, pad="reflect"):
+    """Adjoint of convk_forward w.r.t. x: dy [U,Cout,H,W], w as in the forward -> dx [U,Cin,H,W]  (kmsr_convk_dgrad_f32)."""
+    lib = L.load()
+    dy = dy.contiguous()
+    U, cout, H, W = dy.shape
+    shared = w.ndim == 3
+    cin = w.shape[-3]
+    wT = w.transpose(-1, -3).contiguous()                      # [.., Cout, k*k, Cin]
+    dx = torch.empty((U, cin, H, W), device=dy.device, dtype=torch.float32)
+    with torch.cuda.device(dy.device):
+        L.check(lib.kmsr_convk_dgrad_f32(_convk_desc(U, cin, cout, H, W, k, pad, shared), L.ptr(dy), L.ptr(wT), L.ptr(dx),
+                                         L.current_stream()))
+    return dx
+
+
+def convk_wgrad(x, dy, k, pad="reflect", shared=False):
+    """dw [U,Cin,k*k,Cout] (or [Cin,k*k,Cout] summed over units when shared)  (kmsr_convk_wgrad_f32)."""
+    lib = L.load()
+    x, dy = x.contiguous(), dy.contiguous()
+    U, Cin, H, W = x.shape
+    cout = dy.shape[1]
+    assert dy.shape[0] == U and tuple(dy.shape[2:]) == (H, W)
+    d = _convk_desc(U, Cin, cout, H, W, k, pad, shared)
+    nbytes = lib.kmsr_convk_wgrad_workspace_bytes(d)
+    if nbytes == 0:
+        raise NotImplementedError(f"convk_wgrad: {lib.kmsr_last_error().decode('utf-8', 'replace')}")
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    dw = torch.empty(((Cin, k * k, cout) if shared else (U, Cin, k * k, cout)), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(lib.kmsr_convk_wgrad_f32(d, L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(ws), nbytes, L.current_stream()))
+    return dw
+
+
+class ConvKFunction(torch.autograd.Function):
+    """out = convk(x, w) [+ bias] with the HIP kernels in all three directions (forward, data gradient, weight gradient);
+    the bias gradient is a per-channel sum of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, k, pad):
+        ctx.save_for_backward(x, w)
+        ctx.k, ctx.pad, ctx.has_bias = k, pad, bias is not None
+        return convk_forward(x, w.detach(), k, pad, None if bias is None else bias.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        dx = convk_dgrad(g, w.detach(), ctx.k, ctx.pad) if ctx.needs_input_grad[0] else None
+        dw = convk_wgrad(x, g, ctx.k, ctx.pad, shared=w.ndim == 3) if ctx.needs_input_grad[1] else None
+        db = g.sum(dim=(0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None
+
+
 def _chain_forward(x, W, scales):
     """x [B,C,H,W]; W: list over bands of the 6 layer weights [co,ci,k,k]; scales [B,C,161] or None.
-    Returns [B,C,H/8,W/8] (muti_kernel/networks.py:101-133, single_kernel/networks.py:83-106)."""
+    Returns [B,C,H/8,W/8] (muti_kernel/networks.py:101-133, single_kernel/networks.py:83-106).  Under autograd the
+    three launches are ConvKFunction nodes and the result carries gradients to W and scales."""
     B, Cc, H, Wd = x.shape
     dev = x.device
-    w = [torch.stack([band[l].detach() for band in W]).to(dev) for l in range(6)]      # [C,co,ci,k,k] per layer
+    grad = torch.is_grad_enabled()
+    keep = (lambda t: t) if grad else (lambda t: t.detach())
+    w = [torch.stack([keep(band[l]) for band in W]).to(dev) for l in range(6)]         # [C,co,ci,k,k] per layer
     offs = [0, 32, 64, 96, 128, 160, 161]
     if scales is None:
         s = [torch.ones(B, Cc, offs[l + 1] - offs[l], device=dev) for l in range(6)]
@@ -60,9 +146,14 @@ def _chain_forward(x, W, scales):
     m6 = torch.einsum('coi,bco->bcoi', w[5].reshape(Cc, 1, 32), s[5])
     v = torch.matmul(torch.matmul(m6, m5), m4).reshape(B, Cc, 32) * s[2]                # [B,C,32] over layer-3 outputs
     w3 = torch.einsum('bck,ckit->bcit', v, w[2].reshape(Cc, 32, 32, 9)).reshape(U, 32, 9, 1)
-    h = conv_reflect(x.reshape(U, 1, H, Wd), w1, 7, 32)
-    h = conv_reflect(h, w2, 5, 32)
-    h = conv_reflect(h, w3, 3, 1)
+    if grad:
+        h = ConvKFunction.apply(x.detach().reshape(U, 1, H, Wd), w1, None, 7, "reflect")
+        h = ConvKFunction.apply(h, w2, None, 5, "reflect")
+        h = ConvKFunction.apply(h, w3, None, 3, "reflect")
+    else:
+        h = conv_reflect(x.reshape(U, 1, H, Wd), w1, 7, 32)
+        h = conv_reflect(h, w2, 5, 32)
+        h = conv_reflect(h, w3, 3, 1)
     for _ in range(3):                                                                   # down1..down3 (:114-116)
         h = torch.nn.functional.avg_pool2d(h, kernel_size=2, stride=2)
     return h.reshape(B, Cc, H // 8, Wd // 8)
@@ -115,14 +206,22 @@ class ConditionEncoder(nn.Module):
             self._packed = (key, [pack_conv3x3_weight(c.weight) for c in convs])
         return convs, self._packed[1]
 
-    @torch.no_grad()
     def scales_tensor(self, x):
         """[B, in_ch, 161]: for every band the 6 layers' scales concatenated (the reference returns the same numbers
-        as a list[band][layer] of [B,out_c] tensors, :46-58)."""
-        convs, packs = self._packs()
-        h = x
-        for conv, pw in zip(convs, packs):
-            h = conv3x3(h, pw, conv.out_channels, bias=conv.bias, relu=True, stride=conv.stride[0])
+        as a list[band][layer] of [B,out_c] tensors, :46-58).  Under autograd the convs are Conv3x3Function nodes (HIP
+        forward / dgrad / wgrad; a stride-2 pad-1 conv is the stride-1 conv sampled at even positions)."""
+        if torch.is_grad_enabled():
+            h = x.detach()
+            for conv in (self.encoder[0], self.encoder[2], self.encoder[4]):
+                if conv.stride[0] == 1:
+                    h = Conv3x3Function.apply(h, conv.weight, conv.bias, True)
+                else:
+                    h = torch.relu(Conv3x3Function.apply(h, conv.weight, conv.bias, False)[:, :, ::2, ::2])
+        else:
+            convs, packs = self._packs()
+            h = x
+            for conv, pw in zip(convs, packs):
+                h = conv3x3(h, pw, conv.out_channels, bias=conv.bias, relu=True, stride=conv.stride[0])
         h = h.mean(dim=(2, 3))
         raw = torch.nn.functional.linear(h, self.fc.weight, self.fc.bias)
         return (1.0 + self.scale_gain * torch.tanh(raw)).view(x.shape[0], self.in_ch, sum(self.layer_out_channels))
@@ -163,9 +262,9 @@ class DynamicMultiBandLinearGenerator(nn.Module):
     def _flat_weights(self):
         return torch.stack([torch.cat([w.detach().reshape(-1) for w in band]) for band in self.weight_bands])
 
-    @torch.no_grad()
     def forward(self, x):
-        """:119-133 -- [B,C,H,W] -> [B,C,H/8,W/8]; per-sample, per-band chains with condition-encoder scales."""
+        """:119-133 -- [B,C,H,W] -> [B,C,H/8,W/8]; per-sample, per-band chains with condition-encoder scales.
+        Differentiable w.r.t. the parameters when autograd is enabled (the reference's forward always is)."""
         L.require_gpu()
         return _chain_forward(x, [list(band) for band in self.weight_bands], self.condition_encoder.scales_tensor(x))
 
@@ -174,7 +273,7 @@ class DynamicMultiBandLinearGenerator(nn.Module):
         """:135-202.  x given -> dynamic kernels from its condition scales ([B,C,K,K], or the batch mean [C,K,K]);
         x None -> unit scales ([C,K,K])."""
         co, ci, ks = self._layer_dims()
-        scales = None if x is None else self.condition_encoder.scales_tensor(x)
+        scales = None if x is None else self.condition_encoder.scales_tensor(x)      # no_grad here: the inference convs
         k = compose_kernels(self._flat_weights(), scales, co, ci, ks)
         return k.mean(dim=0) if reduce_batch else k
 
@@ -220,9 +319,8 @@ class MultiBandLinearGenerator(nn.Module):
             convs[-1].weight.zero_()
             convs[-1].weight.fill_(1.0 / self.mid_ch)
 
-    @torch.no_grad()
     def forward(self, x):
-        """single_kernel/networks.py:83-106 -- [B,C,H,W] -> [B,C,H/8,W/8]."""
+        """single_kernel/networks.py:83-106 -- [B,C,H,W] -> [B,C,H/8,W/8]; differentiable when autograd is enabled."""
         L.require_gpu()
         return _chain_forward(x, [[c.weight for c in convs] for convs in self.chains], None)
 
@@ -250,7 +348,6 @@ class DegradationModel(nn.Module):
         self.generator = DynamicMultiBandLinearGenerator(in_ch=in_ch, mid_ch=mid_ch, ks=ks, scale_gain=scale_gain)
         self.noise_estimator = NoiseEstimator(channels=in_ch, init_sigma=noise_init, sigma_max=noise_max)
 
-    @torch.no_grad()
     def forward(self, x):
         clean = self.generator(x)
         noisy, sigma = self.noise_estimator(clean)

@@ -169,10 +169,19 @@ class NoiseEstimator(nn.Module):
         self.noise_seed = 0
         self.noise_offset = 0
 
-    @torch.no_grad()
-    def forward(self, x):
+    def forward(self, x, eps=None):
+        """-> (x + sigma * eps, sigma).  eps: the unit-variance field of the HIP counter-based generator (or a caller-supplied
+        one); with autograd enabled the result carries gradients to x and log_sigma like the reference's (:219-224)."""
         sigma = torch.clamp(torch.exp(self.log_sigma), min=1e-5, max=self.sigma_max)      # :222
         one = torch.ones((1, x.shape[1], 1, 1), device=x.device)
+        if torch.is_grad_enabled() or eps is not None:
+            if eps is None:
+                with torch.no_grad():     # identity blur of zeros + unit-sigma Gaussian epilogue = the eps field itself
+                    eps = degrade_batch(torch.zeros_like(x), one, 1, down="stride", pad="zero", normalize=False,
+                                        sigma=torch.ones((1, x.shape[1]), device=x.device), noise="gaussian",
+                                        seed=kd.rank_seed(self.noise_seed), offset=self.noise_offset)
+                self.noise_offset += 1
+            return x + eps * sigma.view(1, -1, 1, 1), sigma
         # identity blur (1x1 kernel, stride 1) + Gaussian epilogue of the fused kernel
         out = degrade_batch(x, one, 1, down="stride", pad="zero", normalize=False, sigma=sigma.view(1, -1),
                             noise="gaussian", seed=kd.rank_seed(self.noise_seed), offset=self.noise_offset)

@@ -6,9 +6,10 @@ muti_kernel/train_gemini.py:145-254, with the generator side on the HIP kernels.
     save_moe(model, "./moe_kernels")                                     # train_gemini.py:237-251 (same file names)
 
 What runs where: the fused degradation forward, its backward w.r.t. kernels / sigmas (kmsr_degrade_bwd_f32) and the
-selector's 3x3 convs (forward, dgrad, wgrad) are HIP kernels behind the C ABI.  The PatchDiscriminator (7x7 conv 5->64
-on 64x64 LR patches + four 1x1 convs, 0.13 GFLOP per sample, spectral norm, BatchNorm) is expressed as unfold + matmul
-(library GEMMs) with torch autograd: it is the critic, not the path.  Losses are the reference's formulas
+selector's 3x3 convs (forward, dgrad, wgrad) are HIP kernels behind the C ABI.  The PatchDiscriminator's convs (zero-padded
+7x7 5->64 and 1x1 64->64 / 64->1 on the LR patches) run on the small-channel HIP family (kmsr_convk_fwd / dgrad / wgrad_f32,
+shared weights + bias); its spectral normalisation, BatchNorm and LeakyReLU are the stock torch modules (weight-side /
+elementwise on [B,64,h,w] LR maps).  Losses are the reference's formulas
 (muti_kernel/loss.py:6-41).  Data parallel: every rank trains on its own patches; gradients of both networks are
 averaged through kmsr_amd.dist.GradBucket (one flat all-reduce each per step).
 """
@@ -51,19 +52,16 @@ def kernel_regularization(k, alpha=0.5, beta=0.5, gamma=5.0, delta=1.0):
     return alpha * unit_sum + beta * border + gamma * sparse + delta * centre
 
 
-class _GemmConv2d(nn.Conv2d):
-    """nn.Conv2d parameters (so spectral_norm and state_dict keys are the stock ones); the product itself is
-    unfold + matmul -> library GEMMs, zero padding, stride 1."""
+class _HipConv2d(nn.Conv2d):
+    """nn.Conv2d parameters (so spectral_norm and state_dict keys are the stock ones); the convolution itself (zero padding
+    k//2, stride 1) and both of its gradients are the HIP kernels behind kmsr_convk_* (one weight set shared by the batch)."""
 
     def forward(self, x):
-        k, p = self.kernel_size[0], self.padding[0]
-        B, C, H, W = x.shape
-        w = self.weight.view(self.out_channels, -1)
-        cols = x.view(B, C, H * W) if k == 1 else F.unfold(x, k, padding=p)
-        y = torch.matmul(w, cols)
-        if self.bias is not None:
-            y = y + self.bias.view(1, -1, 1)
-        return y.view(B, self.out_channels, H + 2 * p - k + 1, W + 2 * p - k + 1)
+        from .kernelgan import ConvKFunction
+        k = self.kernel_size[0]
+        assert self.stride == (1, 1) and self.padding == (k // 2, k // 2) and self.kernel_size == (k, k)
+        w = self.weight.permute(1, 2, 3, 0).reshape(self.in_channels, k * k, self.out_channels)      # [ci][tap][co]
+        return ConvKFunction.apply(x, w, self.bias, k, "zero")
 
 
 class PatchDiscriminator(nn.Module):
@@ -72,11 +70,11 @@ class PatchDiscriminator(nn.Module):
 
     def __init__(self, in_ch=5, base_ch=64, num_blocks=4):
         super().__init__()
-        layers = [spectral_norm(_GemmConv2d(in_ch, base_ch, 7, 1, 3)), nn.LeakyReLU(0.2, inplace=True)]
+        layers = [spectral_norm(_HipConv2d(in_ch, base_ch, 7, 1, 3)), nn.LeakyReLU(0.2, inplace=True)]
         for _ in range(num_blocks):
-            layers += [spectral_norm(_GemmConv2d(base_ch, base_ch, 1, 1, 0)), nn.BatchNorm2d(base_ch),
+            layers += [spectral_norm(_HipConv2d(base_ch, base_ch, 1, 1, 0)), nn.BatchNorm2d(base_ch),
                        nn.LeakyReLU(0.2, inplace=True)]
-        layers.append(spectral_norm(_GemmConv2d(base_ch, 1, 1, 1, 0)))
+        layers.append(spectral_norm(_HipConv2d(base_ch, 1, 1, 1, 0)))
         self.net = nn.Sequential(*layers)
 
     def forward(self, x):

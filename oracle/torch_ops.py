@@ -39,3 +39,20 @@ def vb_torch(x, kernels, stride=4):
     ks = k.shape[-1]
     y = F.conv2d(x.reshape(1, B * Cb, H, W), k.reshape(B * Cb, 1, ks, ks), padding=ks // 2, groups=B * Cb)
     return y.reshape(B, Cb, H, W)[:, :, ::stride, ::stride]
+
+
+def convk_torch(x, w, k, pad="reflect", bias=None, dtype=torch.float64):
+    """The KernelGAN layer (muti_kernel/networks.py:108-112: F.pad(mode='reflect') + F.conv2d with per-unit weights) and the
+    critic's zero-padded conv (muti_kernel/networks.py:257-264), in the kmsr_convk_* weight layout:
+    x [U,Cin,H,W]; w [U,Cin,k*k,Cout] (per unit) or [Cin,k*k,Cout] (shared) -> [U,Cout,H,W].  Differentiable (torch
+    autograd), float64 by default: the checker of kmsr_convk_fwd / dgrad / wgrad_f32."""
+    x = x.to(dtype)
+    w = w.to(dtype)
+    U, Cin, H, W = x.shape
+    p = k // 2
+    xp = F.pad(x, (p, p, p, p), mode="reflect") if (pad == "reflect" and p) else F.pad(x, (p, p, p, p))
+    if w.ndim == 3:
+        wt = w.permute(2, 0, 1).reshape(w.shape[2], Cin, k, k)
+        return F.conv2d(xp, wt, None if bias is None else bias.to(dtype))
+    outs = [F.conv2d(xp[u:u + 1], w[u].permute(2, 0, 1).reshape(w.shape[3], Cin, k, k)) for u in range(U)]
+    return torch.cat(outs)

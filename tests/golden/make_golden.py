@@ -279,7 +279,7 @@ def main():
             print(f"{f:28s} {os.path.getsize(os.path.join(OUT, f)) / 1024:9.1f} KiB")
 
 
-if __name__ == "__main__" and "--patch-cutter" not in sys.argv and "--moe-backward" not in sys.argv:
+if __name__ == "__main__" and not ({"--patch-cutter", "--moe-backward", "--kernelgan-train"} & set(sys.argv)):
     main()
 
 
@@ -392,8 +392,140 @@ def make_moe_backward_golden():
     print({k: v.shape for k, v in out.items()})
 
 
-if __name__ == "__main__" and "--moe-backward" in sys.argv:
+def _grad_record(out, prefix, named_grads, full):
+    """Store a gradient set: tensors whose name is in `full` whole, every tensor as (sum, sum|.|, sum of squares) in float64."""
+    for name, g in named_grads:
+        g = g.detach()
+        out[f"{prefix}chk__{name}"] = np.array([g.double().sum().item(), g.double().abs().sum().item(),
+                                               g.double().pow(2).sum().item()])
+        if name in full:
+            out[f"{prefix}full__{name}"] = g.numpy().copy()
+
+
+def make_kernelgan_train_golden():
+    """One iteration of each KernelGAN trainer, run with the reference's own classes and loss functions in the statement
+    order of muti_kernel/train.py:262-286 and single_kernel/train.py:269-308 (the loops live inside main() and read files from
+    H:\\..., so the statements are replayed here on seeded inputs).  Weights: the state_dicts already stored in kernelgan.npz;
+    critic: PatchDiscriminator(in_ch=5) under torch.manual_seed(0) (its state_dict is stored in moe_backward.npz as D__*).
+    torch.randn_like inside NoiseEstimator.forward is replaced by a seeded eps field so the noisy fake is reproducible."""
+    m = _import_reference()
+    k = os.path.join(REF, "kernel_from_lr_gan")
+    sloss = _load("ref_single_loss", os.path.join(k, "single_kernel", "loss.py"))
+    KG = np.load(os.path.join(OUT, "kernelgan.npz"))
+    out = {}
+    # ---------------------------------------------------------------- multi-kernel trainer
+    nets, L = m["mnet"], m["mloss"]
+    model = nets.DegradationModel(in_ch=5, mid_ch=32, ks=(7, 5, 3, 1, 1, 1), scale_gain=0.1, noise_init=0.3, noise_max=1.2)
+    model.load_state_dict({n[len("muti_sd__"):]: torch.from_numpy(KG[n]) for n in KG.files if n.startswith("muti_sd__")})
+    torch.manual_seed(0)
+    D = nets.PatchDiscriminator(in_ch=5, base_ch=64, num_blocks=4)
+    opt_D = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    opt_G = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    patches = torch.from_numpy(KG["muti__x"])                                            # [2,5,64,64]
+    real_ds = landsat_like((2, 5, 8, 8), 41) / 100.0
+    eps = torch.randn(2, 5, 8, 8, generator=torch.Generator().manual_seed(42))
+    target_sigma = torch.tensor([0.55, 0.72, 0.83, 0.63, 0.19])
+    real_randn_like = torch.randn_like
+    torch.randn_like = lambda t, **kw: eps.clone()
+    try:
+        clean_fake, fake_ds, sigma = model(patches)
+    finally:
+        torch.randn_like = real_randn_like
+    D.train(); model.train()
+    loss_D = L.lsgan_d_loss(D(real_ds), D(fake_ds.detach()))
+    opt_D.zero_grad(); loss_D.backward()
+    _grad_record(out, "muti_D_", [(n, p.grad) for n, p in D.named_parameters()], {"net.0.weight_orig", "net.0.bias", "net.2.weight_orig",
+                                                                                "net.3.weight", "net.14.weight_orig"})
+    opt_D.step()
+    pred_fake = D(fake_ds)
+    loss_G_adv = L.lsgan_g_loss(pred_fake)
+    ks_band = model.generator.extract_effective_kernels(patches, reduce_batch=True)
+    loss_reg = torch.mean(torch.stack([L.kernel_regularization(k=ks_band[i], alpha=0.5, beta=0.5, gamma=5.0, delta=1.0)
+                                       for i in range(ks_band.shape[0])]))
+    loss_noise = L.noise_reg_loss(sigma, target=target_sigma, mode='l2')
+    loss_G = loss_G_adv + loss_reg + 20.0 * loss_noise
+    out["muti_reg_requires_grad"] = np.array([int(loss_reg.requires_grad)])
+    opt_G.zero_grad(); loss_G.backward()
+    full = {"generator.weight_bands.0.%d" % l for l in range(6)} | {"generator.weight_bands.3.1", "generator.weight_bands.4.5",
+            "generator.condition_encoder.encoder.0.weight", "generator.condition_encoder.encoder.0.bias",
+            "generator.condition_encoder.encoder.4.bias", "generator.condition_encoder.fc.bias", "noise_estimator.log_sigma"}
+    _grad_record(out, "muti_G_", [(n, p.grad) for n, p in model.named_parameters()], full)
+    opt_G.step()
+    out["muti_losses"] = np.array([loss_D.item(), loss_G_adv.item(), loss_reg.item(), loss_noise.item()])
+    out["muti_clean"] = clean_fake.detach().numpy()
+    out["muti_sigma"] = sigma.detach().numpy()
+    out["muti_pred_fake_G"] = pred_fake.detach().numpy()
+    out["muti_after_G__weight_bands.0.0"] = model.generator.weight_bands[0][0].detach().numpy().copy()
+    out["muti_after_G__log_sigma"] = model.noise_estimator.log_sigma.detach().numpy().copy()
+    out["muti_after_D__net.0.weight_orig"] = D.net[0].weight_orig.detach().numpy().copy()
+    # ---------------------------------------------------------------- single-kernel trainer
+    snets = m["snet"]
+    G = snets.MultiBandLinearGenerator(in_ch=5, mid_ch=32)
+    G.load_state_dict({n[len("single_perturbed_sd__"):]: torch.from_numpy(KG[n]) for n in KG.files
+                       if n.startswith("single_perturbed_sd__")})
+    torch.manual_seed(0)
+    D = snets.PatchDiscriminator(in_ch=5, base_ch=64, num_blocks=4)
+    opt_D = torch.optim.Adam(D.parameters(), lr=4e-4, betas=(0.5, 0.999))
+    opt_G = torch.optim.Adam(G.parameters(), lr=4e-4, betas=(0.5, 0.999))
+    from torch.nn.utils import clip_grad_norm_
+    patches = landsat_like((2, 5, 64, 64), 31) / 100.0
+    real_ds = landsat_like((2, 5, 8, 8), 43) / 100.0
+    fake_ds = G(patches)
+    D.train(); G.train()
+    loss_D = sloss.lsgan_d_loss(D(real_ds), D(fake_ds.detach()))
+    opt_D.zero_grad(); loss_D.backward()
+    gn_D = clip_grad_norm_(parameters=D.parameters(), max_norm=20.0)
+    opt_D.step()
+    pred_fake = D(fake_ds)
+    loss_G_adv = sloss.lsgan_g_loss(pred_fake)
+    ks_band = G.extract_effective_kernels()
+    loss_reg = torch.mean(torch.stack([sloss.kernel_regularization(k=ks_band[i], alpha=0.5, beta=0.5, gamma=5.0, delta=1.0,
+                                                                   epsilon=3.0) for i in range(ks_band.shape[0])]))
+    loss_G = loss_G_adv + 0.002 * loss_reg
+    opt_G.zero_grad(); loss_G.backward()
+    _grad_record(out, "single_G_preclip_", [(n, p.grad.clone()) for n, p in G.named_parameters()],
+                 {"chains.0.%d.weight" % l for l in range(6)} | {"chains.2.1.weight", "chains.4.5.weight"})
+    gn_G = clip_grad_norm_(parameters=G.parameters(), max_norm=20.0)
+    opt_G.step()
+    out["single_losses"] = np.array([loss_D.item(), loss_G_adv.item(), loss_reg.item(), float(gn_D), float(gn_G)])
+    out["single_fake"] = fake_ds.detach().numpy()
+    out["single_after_G__chains.0.0.weight"] = G.chains[0][0].weight.detach().numpy().copy()
+    out["single_after_G__chains.1.2.weight"] = G.chains[1][2].weight.detach().numpy().copy()
+    # ---------------------------------------------------------------- the trainers' samplers (global torch RNG draw order)
+    import tempfile
+    sys.path.insert(0, os.path.join(k, "muti_kernel"))
+    mtrain = _load("ref_muti_train", os.path.join(k, "muti_kernel", "train.py"))
+    sys.path.pop(0)
+    sys.modules.pop("networks", None); sys.modules.pop("loss", None)
+    sys.path.insert(0, os.path.join(k, "single_kernel"))
+    strain = _load("ref_single_train", os.path.join(k, "single_kernel", "train.py"))
+    sys.path.pop(0)
+    with tempfile.TemporaryDirectory() as td:
+        for i in range(6):
+            np.save(os.path.join(td, f"p{i}.npy"), (landsat_like((5, 40, 44), 60 + i) / 100.0).numpy())
+        files, osz = mtrain.load_patches_from_folder(td)
+        torch.manual_seed(7)
+        a = mtrain.sample_patches_from_files(files, batch_size=4, target_size=32, original_size=osz)
+        b = mtrain.sample_patches_from_files(files, batch_size=3, target_size=40, original_size=osz)
+    out["sampler_muti_a"] = a.numpy()[:, :, ::8, ::8].copy()
+    out["sampler_muti_b"] = b.numpy()[:, :, ::8, ::8].copy()
+    out["sampler_muti_osz"] = np.array([osz])
+    torch.manual_seed(8)
+    full = torch.stack([landsat_like((5, 40, 44), 70 + i) / 100.0 for i in range(3)])
+    out["sampler_single_crop"] = strain.crop_patches(full, crop_size=32).numpy()[:, :, ::8, ::8].copy()
+    out["note"] = np.array("muti_kernel/train.py:262-286 + single_kernel/train.py:269-308, one iteration each; inputs: kernelgan.npz "
+                           "weights, muti__x / landsat_like((2,5,64,64),31)/100, real_ds landsat_like((2,5,8,8),41|43)/100, "
+                           "eps randn seed 42, D = PatchDiscriminator under manual_seed(0)")
+    np.savez_compressed(os.path.join(OUT, "kernelgan_train.npz"), **out)
+    print("kernelgan_train.npz", os.path.getsize(os.path.join(OUT, "kernelgan_train.npz")) // 1024, "KiB;",
+          "muti losses", out["muti_losses"], "single", out["single_losses"], "reg requires grad:", out["muti_reg_requires_grad"])
+
+
+if __name__ == "__main__" and "--kernelgan-train" in sys.argv:
+    make_kernelgan_train_golden()
+elif __name__ == "__main__" and "--moe-backward" in sys.argv:
     make_moe_backward_golden()
 elif __name__ == "__main__":
     make_patch_cutter_golden()
     make_moe_backward_golden()
+    make_kernelgan_train_golden()

@@ -12,6 +12,14 @@ pytestmark = pytest.mark.gpu
 KG = golden("kernelgan.npz")
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """These are the inference launches (the reference calls them under torch.no_grad(), muti train.py:118, networks.py:135);
+    the differentiable path is tested in test_kernelgan_train_gpu.py."""
+    with torch.no_grad():
+        yield
+
+
 def _sd(prefix):
     return {k[len(prefix):]: torch.from_numpy(np.asarray(KG[k])) for k in KG.files if k.startswith(prefix)}
 

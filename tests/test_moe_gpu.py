@@ -94,10 +94,22 @@ def test_noise_estimator(gpu_device):
     ne = kmsr_amd.NoiseEstimator(channels=5, init_sigma=0.3, sigma_max=1.2).cuda()
     ne.noise_seed = 3
     x = torch.from_numpy(landsat_like((2, 5, 32, 32), 23)).cuda()
-    noisy, sigma = ne(x)
+    with torch.no_grad():
+        noisy, sigma = ne(x)                      # fused launch: identity blur + Gaussian epilogue
     assert_close(sigma.cpu().numpy(), golden("kernelgan.npz")["muti__noise_sigma"], rtol=1e-6, what="sigma")
     want = oracle.add_gaussian_noise(x.cpu().numpy(), np.tile(sigma.cpu().numpy(), 2), seed=3, offset=0)
     assert_close(noisy.cpu().numpy(), want, rtol=1e-6, atol=2e-6, what="noise estimator")
+    # differentiable form (the KernelGAN trainer's): same eps stream, gradients to x and log_sigma
+    ne.noise_offset = 0
+    xg = x.clone().requires_grad_(True)
+    noisy_g, sigma_g = ne(xg)
+    assert_close(noisy_g.detach().cpu().numpy(), want, rtol=1e-6, atol=2e-6, what="noise estimator (autograd form)")
+    gsel = torch.randn_like(noisy_g)
+    (noisy_g * gsel).sum().backward()
+    assert torch.equal(xg.grad, gsel)
+    eps = (noisy_g.detach() - x) / sigma_g.detach().view(1, -1, 1, 1)
+    want_ls = (gsel * eps).sum(dim=(0, 2, 3)) * sigma_g.detach()          # d sigma / d log_sigma = sigma inside the clamp
+    assert_close(ne.log_sigma.grad.cpu().numpy(), want_ls.cpu().numpy(), rtol=2e-4, atol=1e-4, what="d log_sigma")
     ne2 = kmsr_amd.NoiseEstimator(channels=5, init_sigma=5.0, sigma_max=0.2)
     assert float(torch.clamp(torch.exp(ne2.log_sigma.detach()), 1e-5, 0.2).max()) == pytest.approx(0.2)
 
