@@ -50,9 +50,17 @@ def _convk_desc(U, Cin, Cout, H, W, k, pad, shared):
     return d
 
 
+def _on_gpu(*ts):
+    L.require_gpu()
+    for t in ts:
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32):
+            raise L.KmsrError("the convk kernels take float32 CUDA tensors (no CPU fallback)")
+
+
 def convk_forward(x, w, k, pad="reflect", bias=None):
     """x [U,Cin,H,W]; w [U,Cin,k*k,Cout] (per unit) or [Cin,k*k,Cout] (shared) -> [U,Cout,H,W]  (kmsr_convk_fwd_f32)."""
     lib = L.load()
+    _on_gpu(x, w, bias)
     x, w = x.contiguous(), w.contiguous()
     U, Cin, H, W = x.shape
     shared = w.ndim == 3
@@ -71,6 +79,7 @@ def convk_forward(x, w, k, pad="reflect", bias=None):
 def convk_dgrad(dy, w, k, pad="reflect"):
     """Adjoint of convk_forward w.r.t. x: dy [U,Cout,H,W], w as in the forward -> dx [U,Cin,H,W]  (kmsr_convk_dgrad_f32)."""
     lib = L.load()
+    _on_gpu(dy, w)
     dy = dy.contiguous()
     U, cout, H, W = dy.shape
     shared = w.ndim == 3
@@ -86,6 +95,7 @@ def convk_dgrad(dy, w, k, pad="reflect"):
 def convk_wgrad(x, dy, k, pad="reflect", shared=False):
     """dw [U,Cin,k*k,Cout] (or [Cin,k*k,Cout] summed over units when shared)  (kmsr_convk_wgrad_f32)."""
     lib = L.load()
+    _on_gpu(x, dy)
     x, dy = x.contiguous(), dy.contiguous()
     U, Cin, H, W = x.shape
     cout = dy.shape[1]

@@ -151,6 +151,27 @@ def _critic():
 
 
 @pytest.mark.gpu
+def test_patch_discriminator_matches_reference(gpu_device):
+    """PatchDiscriminator (muti_kernel/networks.py:250-268) on the HIP convs: eval and train-mode (spectral-norm power
+    iteration + batch-statistics BN) outputs and a weight gradient against the reference's."""
+    MB = golden("moe_backward.npz")
+    D = _critic()
+    xd = torch.randn(2, 5, 16, 16, generator=torch.Generator().manual_seed(36)).cuda()
+    D.eval()
+    with torch.no_grad():
+        assert_close(D(xd).cpu().numpy(), MB["D_eval_out"], rtol=1e-4, atol=1e-5, what="D eval output")
+    D.train()
+    yd = D(xd)
+    yd.pow(2).mean().backward()
+    assert_close(yd.detach().cpu().numpy(), MB["D_train_out"], rtol=1e-4, atol=1e-5, what="D train output")
+    assert_close(D.net[0].weight_u.cpu().numpy(), MB["D_train_u0"], rtol=1e-5, atol=1e-6, what="spectral-norm u after one step")
+    assert_close(D.net[0].weight_orig.grad.cpu().numpy(), MB["D_train_d_w0"], rtol=1e-3,
+                 atol=1e-4 * np.abs(MB["D_train_d_w0"]).max(), what="d weight_orig")
+    with pytest.raises(kmsr_amd._lib.KmsrError):
+        kmsr_amd.PatchDiscriminator(5)(torch.zeros(1, 5, 8, 8))            # no CPU fallback
+
+
+@pytest.mark.gpu
 def test_multi_kernel_trainer_iteration_matches_reference(gpu_device):
     """muti_kernel/train.py:262-286: D step, Adam, G step through the updated critic; tolerance 2e-4 of each tensor's scale
     (fp32 chains of 6 convs + critic + BatchNorm batch statistics on 2x8x8 maps, different summation orders)."""

@@ -236,27 +236,16 @@ def test_moe_trainer_losses_match_reference():
     assert_close(got, MB["lsgan"], rtol=1e-6, atol=1e-7, what="lsgan losses")
 
 
-def test_patch_discriminator_matches_reference():
-    """PatchDiscriminator (muti_kernel/networks.py:250-268): the reference's state_dict loads key for key; eval and
-    train-mode (spectral-norm power iteration + batch-statistics BN) outputs and a weight gradient match."""
+def test_patch_discriminator_state_dict_keys():
+    """PatchDiscriminator (muti_kernel/networks.py:250-268): the reference's state_dict loads key for key.  Its convolutions
+    are HIP-only now (kmsr_convk_*); outputs / gradients are compared on the GPU in tests/test_kernelgan_train_gpu.py."""
     import torch
     import kmsr_amd
     MB = golden("moe_backward.npz")
     sd = {k[3:]: torch.from_numpy(np.asarray(MB[k])) for k in MB.files if k.startswith("D__")}
     D = kmsr_amd.PatchDiscriminator(in_ch=5)
     assert set(D.state_dict().keys()) == set(sd.keys())
-    D.load_state_dict(sd)
-    xd = torch.randn(2, 5, 16, 16, generator=torch.Generator().manual_seed(36))
-    D.eval()
-    with torch.no_grad():
-        assert_close(D(xd).numpy(), MB["D_eval_out"], rtol=1e-4, atol=1e-5, what="D eval output")
-    D.train()
-    yd = D(xd)
-    yd.pow(2).mean().backward()
-    assert_close(yd.detach().numpy(), MB["D_train_out"], rtol=1e-4, atol=1e-5, what="D train output")
-    assert_close(D.net[0].weight_u.numpy(), MB["D_train_u0"], rtol=1e-5, atol=1e-6, what="spectral-norm u after one step")
-    assert_close(D.net[0].weight_orig.grad.numpy(), MB["D_train_d_w0"], rtol=1e-3,
-                 atol=1e-4 * np.abs(MB["D_train_d_w0"]).max(), what="d weight_orig")
+    D.load_state_dict(sd, strict=True)
 
 
 # ------------------------------------------------------------------ stock-torch form of the degradation (bench.py's second CPU baseline)
