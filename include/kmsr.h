@@ -158,8 +158,12 @@ typedef struct kmsr_conv3x3_desc {
     int32_t stride;          /* 1 or 2                                                               */
     int32_t relu;            /* 0/1                                                                  */
     int32_t pixel_shuffle;   /* 0/1 (stride must be 1)                                               */
-    uint32_t flags;          /* reserved, 0                                                          */
+    uint32_t flags;          /* KMSR_CONV_FLAG_* (0 for the plain forward)                           */
 } kmsr_conv3x3_desc;
+/* `residual` is not added but used as a ReLU mask: out = residual > 0 ? conv : 0 -- the data gradient through
+ * y = relu(conv(x)) computed in the gradient convolution's own epilogue (mask source = the saved y).  Honoured by
+ * kmsr_conv3x3_winov_fwd[_ex]_f32; the other entry points reject it with KMSR_E_UNSUPPORTED.               */
+#define KMSR_CONV_FLAG_RELU_MASK 1u
 
 /* number of floats in the packed weight buffer for (Cin, Cout) */
 size_t kmsr_conv3x3_packed_weight_floats(int32_t Cin, int32_t Cout);
@@ -233,6 +237,14 @@ int kmsr_conv3x3_winov_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int
                                         void* stream);
 int kmsr_conv3x3_winov_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
                                const float* residual, float* out, void* stream);
+/* Training-step variant: honours KMSR_CONV_FLAG_RELU_MASK and, when chan_sum != NULL (not with pixel_shuffle), also writes
+ * per-channel partial sums of the tensor it stores: chan_sum[item][4][64] with item = (n * ceil(Cout/64) + cg) * tiles + tile
+ * (kmsr_conv3x3_winov_chan_sum_floats(d) floats, every entry written, padding channels 0).  Summing over (n, tile, 4) gives
+ * sum_{n,y,x} out[n,c,y,x] -- the bias gradient of the layer whose output gradient this launch produces -- without re-reading
+ * the tensor; the partials are formed in a fixed order (run-to-run identical). */
+size_t kmsr_conv3x3_winov_chan_sum_floats(const kmsr_conv3x3_desc* d);
+int kmsr_conv3x3_winov_fwd_ex_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
+                                  const float* residual, float* out, float* chan_sum, void* stream);
 
 /* ============================================================================================
  * 5x5 convolution (zero padding 2) with PixelShuffle(4) fused into the store -- the COLLAPSED SR upsampler.

@@ -53,6 +53,7 @@ class ConvKDesc(C.Structure):
 
 
 CONVK_REFLECT, CONVK_ZERO = 0, 1
+CONV_FLAG_RELU_MASK = 1
 
 _lib = None
 
@@ -77,6 +78,8 @@ SYMBOLS = {
     "kmsr_conv3x3_wgrad_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _sz, _vp]),
     "kmsr_conv3x3_wino_packed_weight_floats": (_sz, [_i32, _i32]),
     "kmsr_conv3x3_wino_pack_weights_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "kmsr_conv3x3_winov_chan_sum_floats": (_sz, [C.POINTER(Conv3x3Desc)]),
+    "kmsr_conv3x3_winov_fwd_ex_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kmsr_conv3x3_wino_fwd_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "kmsr_conv3x3_bf16_packed_weight_elems": (_sz, [_i32, _i32]),
     "kmsr_conv3x3_bf16_pack_weights": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -443,6 +443,7 @@ extern "C" int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, 
     if (!d) return fail(KMSR_E_BADARG, "null descriptor");
     if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return fail(KMSR_E_BADARG, "bad conv shape");
     if (d->stride != 1 && d->stride != 2) return fail(KMSR_E_UNSUPPORTED, "conv3x3 stride %d not supported (1 or 2)", d->stride);
+    if (d->flags) return fail(KMSR_E_UNSUPPORTED, "conv flags 0x%x are honoured by kmsr_conv3x3_winov_fwd_ex_f32 only", d->flags);
     if (d->stride == 2 && d->pixel_shuffle) return fail(KMSR_E_UNSUPPORTED, "pixel_shuffle needs stride 1");
     if (d->pixel_shuffle && (d->Cout % 4)) return fail(KMSR_E_SHAPE, "pixel_shuffle needs Cout %% 4 == 0 (Cout=%d)", d->Cout);
     if (d->pixel_shuffle && residual) return fail(KMSR_E_BADARG, "residual is not supported together with pixel_shuffle");

@@ -61,41 +61,38 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(const float* __re
         tpos[j] = 128 + (e & 7); tci[j] = e >> 3; trr[j] = tpos[j] / XC; tcc[j] = tpos[j] % XC;
     }
     float dyr[NDY], xr[32], xt[2];
+    // Staging loads are buffer loads: one descriptor per (image, 64-channel group) whose record count ends at the group's last
+    // real channel, a per-thread byte offset of the pixel (or an out-of-range sentinel for halo positions outside the image)
+    // plus a wave-uniform channel stride.  The range check returns 0 for padding pixels AND for channels past Cin / Cout, so
+    // a load costs one v_add instead of a predicated 64-bit address (this kernel's matrix pipe shares its issue slots with VALU).
+    const unsigned HWb = (unsigned)HW * 4u;
+    constexpr unsigned OOB = 0x80000000u;
     auto load_stage = [&](int s) {
         const int n = s / p.n_stages, t = s % p.n_stages;
         const int y0 = (t / p.tiles_x) * WR, x0 = (t % p.tiles_x) * WC;
-        const int co_left = p.Cout - cog * 64, ci_left = p.Cin - cig * 64;
-        const float* __restrict__ dyn = dyg + ((long long)n * p.Cout + cog * 64) * HW;
-        const float* __restrict__ xn = xg + ((long long)n * p.Cin + cig * 64) * HW;
+        const int co_n = min(p.Cout - cog * 64, 64), ci_n = min(p.Cin - cig * 64, 64);
+        const auto rdy = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(dyg + ((long long)n * p.Cout + cog * 64) * HW), 0, (unsigned)co_n * HWb, 0x00020000);
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(xg + ((long long)n * p.Cin + cig * 64) * HW), 0, (unsigned)ci_n * HWb, 0x00020000);
         {
             const int y = y0 + dr, x = x0 + dc;
-            const bool pok = y < H && x < W;
-            const long long poff = pok ? (long long)y * W + x : 0;
+            const unsigned voff = (y < H && x < W) ? (unsigned)(y * W + x) * 4u : OOB;
 #pragma unroll
-            for (int q = 0; q < NDY; ++q) {
-                const int co = 4 * q + dcs;
-                const bool ok = pok && co < co_left;
-                const float v = dyn[ok ? co * HW + poff : 0];
-                dyr[q] = ok ? v : 0.f;
-            }
+            for (int q = 0; q < NDY; ++q)
+                dyr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, voff + (unsigned)(4 * q + dcs) * HWb, 0, 0));
         }
         {
             const int y = y0 - 1 + xrr, x = x0 - 1 + xcc;
-            const bool pok = y >= 0 && y < H && x >= 0 && x < W;
-            const long long poff = pok ? (long long)y * W + x : 0;
+            const unsigned voff = (y >= 0 && y < H && x >= 0 && x < W) ? (unsigned)(y * W + x) * 4u : OOB;
 #pragma unroll
-            for (int q = 0; q < 32; ++q) {
-                const int ci = 2 * q + xcs;
-                const bool ok = pok && ci < ci_left;
-                const float v = xn[ok ? ci * HW + poff : 0];
-                xr[q] = ok ? v : 0.f;
-            }
+            for (int q = 0; q < 32; ++q)
+                xr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff + (unsigned)(2 * q + xcs) * HWb, 0, 0));
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int yy = y0 - 1 + trr[j], xx = x0 - 1 + tcc[j];
-                const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W && tci[j] < ci_left;
-                const float v = xn[ok ? tci[j] * HW + (long long)yy * W + xx : 0];
-                xt[j] = ok ? v : 0.f;
+                const unsigned vo = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (unsigned)(yy * W + xx) * 4u : OOB;
+                xt[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo + (unsigned)tci[j] * HWb, 0, 0));
             }
         }
     };
@@ -358,6 +355,8 @@ extern "C" int kmsr_conv3x3_wgrad_f32(const kmsr_conv3x3_desc* d, const float* x
     const size_t need = kmsr_conv3x3_wgrad_workspace_bytes(d);
     if (!workspace || workspace_bytes < need) return fail(KMSR_E_NOMEM, "wgrad workspace %zu B < required %zu B", workspace_bytes, need);
     if ((long long)std::max(d->Cin, d->Cout) * d->H * d->W >= (1ll << 31)) return fail(KMSR_E_UNSUPPORTED, "per-image tensor exceeds 2^31 elements");
+    if ((long long)d->H * d->W * 4 * 64 >= (1ll << 31))       // buffer-load byte offsets of one 64-channel group are 32-bit
+        return fail(KMSR_E_UNSUPPORTED, "wgrad: H*W = %lld exceeds 2^23 pixels per plane", (long long)d->H * d->W);
     WgradParams p{};
     p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
     p.tiles_x = ceil_div(d->W, WC); p.tiles_y = ceil_div(d->H, WR); p.n_stages = p.tiles_x * p.tiles_y;

@@ -294,6 +294,7 @@ extern "C" int kmsr_conv3x3_wino_fwd_f32(const kmsr_conv3x3_desc* d, const float
     if (!d) return fail(KMSR_E_BADARG, "null descriptor");
     if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return fail(KMSR_E_BADARG, "bad conv shape");
     if (d->stride != 1) return fail(KMSR_E_UNSUPPORTED, "winograd conv needs stride 1");
+    if (d->flags) return fail(KMSR_E_UNSUPPORTED, "conv flags 0x%x are honoured by kmsr_conv3x3_winov_fwd_ex_f32 only", d->flags);
     if (d->W % 2) return fail(KMSR_E_UNSUPPORTED, "winograd conv needs an even width (W=%d): patch rows are fetched as aligned float2", d->W);
     if (reinterpret_cast<uintptr_t>(x) % 8 || reinterpret_cast<uintptr_t>(out) % 8 || reinterpret_cast<uintptr_t>(residual) % 8)
         return fail(KMSR_E_BADARG, "winograd conv needs 8-byte aligned tensors");

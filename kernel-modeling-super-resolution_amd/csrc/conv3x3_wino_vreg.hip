@@ -61,6 +61,7 @@ __device__ __attribute__((aligned(16))) float g_zero_page[4];   // zero-initiali
 struct WinoVParams {
     int N, Cin, H, W, Cout;            // stride 1: Ho = H, Wo = W
     int tiles_x, tiles, cgs, nchunks, relu, n_items;
+    int res_mask;                      // the skip tensor is a ReLU mask source: out = res > 0 ? conv : 0 (instead of conv + res)
 };
 
 // packed[cg][chunk][step][cb16][m][lane][jj] = (G g G^T)[xi = 4m + jj] for
@@ -112,12 +113,13 @@ __device__ __forceinline__ void wait_dma() {      // all but the N newest vector
 
 struct PatchPair { f32x2 p[4]; };      // one aligned column pair of the 4 patch rows (4 ds_read_b64)
 
-template <bool PS>
+template <bool PS, bool TRAIN>     // TRAIN: the training-step epilogue extras (ReLU-mask skip tensor, per-channel sums); never with PS
 __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float* __restrict__ xg,
                                                                     const float* __restrict__ wpk,
                                                                     const float* __restrict__ bias,
                                                                     const float* __restrict__ res,
-                                                                    float* __restrict__ out, WinoVParams p) {
+                                                                    float* __restrict__ out, float* __restrict__ csum,
+                                                                    WinoVParams p) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, t16 = lane & 15, kq = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -327,11 +329,17 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
     // Skip tensor: plain loads to registers, placed so that vmcnt (which retires in order) never makes them wait for fresh DMA
     // or for stores: channel block 0's values are requested right after the last chunk's barrier, BEFORE that chunk's DMA
     // instructions; channel block 1's after block 0's outputs are computed (its accumulators are dead) and BEFORE block 0's stores.
-    struct ItemPos { int n, cg, y0, x0; };
+    struct ItemPos { int n, cg, y0, x0, item; };
     auto item_pos = [&](int item) {
         const int tile = item % p.tiles, rest = item / p.tiles;
         return ItemPos{rest / p.cgs, rest % p.cgs, (tile / p.tiles_x) * (2 * TROWS) + 2 * tb,
-                       (tile % p.tiles_x) * (2 * TCOLS) + 2 * (tc0 + t16)};   // this lane's 2x2 output pixels: rows y0, y0+1, columns x0, x0+1
+                       (tile % p.tiles_x) * (2 * TCOLS) + 2 * (tc0 + t16), item};   // this lane's 2x2 output pixels: rows y0, y0+1, columns x0, x0+1
+    };
+    auto row_sum16 = [&](float v) {      // sum over the 16 lanes of a DPP row (= the 16 tile columns), valid in lane 15 of the row
+#define KMSR_ROW_SHR(SH) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + SH, 0xf, 0xf, true))
+        KMSR_ROW_SHR(1); KMSR_ROW_SHR(2); KMSR_ROW_SHR(4); KMSR_ROW_SHR(8);
+#undef KMSR_ROW_SHR
+        return v;
     };
     auto fetch_residual = [&](const ItemPos& ip, int cbi, f32x2 (&rr)[2][4]) {
         if constexpr (!PS) {
@@ -388,15 +396,29 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
                     }
             }
         } else {
+            float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     f32x2 v = Y[a][r];
-                    if (res) v = f32x2{v.x + rr[a][r].x, v.y + rr[a][r].y};
-                    if (xok && ip.y0 + a < H && co0 + r < p.Cout)
+                    if (res) {                                               // block-uniform, as is p.res_mask
+                        if (TRAIN && p.res_mask) v = f32x2{rr[a][r].x > 0.f ? v.x : 0.f, rr[a][r].y > 0.f ? v.y : 0.f};
+                        else v = f32x2{v.x + rr[a][r].x, v.y + rr[a][r].y};
+                    }
+                    if (xok && ip.y0 + a < H && co0 + r < p.Cout) {
                         *reinterpret_cast<f32x2*>(out + (((long long)ip.n * p.Cout + co0 + r) * H + ip.y0 + a) * W + ip.x0) = v;
+                        if constexpr (TRAIN) cs[r] += v.x + v.y;
+                    }
                 }
+            // per-channel sums of what this wave just stored (the bias gradient of the layer that consumes this tensor as its
+            // output gradient): 16 tile columns reduced in the DPP row, one float4 per (item, tile quarter, 4-channel group);
+            // fixed order -> run-to-run identical
+            if (TRAIN && csum) {                                             // block-uniform
+                const f32x4 t = f32x4{row_sum16(cs[0]), row_sum16(cs[1]), row_sum16(cs[2]), row_sum16(cs[3])};
+                if (t16 == 15)
+                    *reinterpret_cast<f32x4*>(csum + ((long long)ip.item * 4 + tq) * VCO + (2 * hh + cbi) * 16 + 4 * kq) = t;
+            }
         }
     };
 
@@ -451,9 +473,25 @@ extern "C" int kmsr_conv3x3_winov_pack_weights_f32(const float* w, int32_t Cin, 
     return KMSR_OK;
 }
 
+extern "C" size_t kmsr_conv3x3_winov_chan_sum_floats(const kmsr_conv3x3_desc* d) {
+    if (!d || d->N <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return 0;
+    return (size_t)ceil_div(d->W, 2 * TCOLS) * ceil_div(d->H, 2 * TROWS) * ceil_div(d->Cout, VCO) * d->N * 4 * VCO;
+}
+
 extern "C" int kmsr_conv3x3_winov_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w,
                                           const float* bias, const float* residual, float* out, void* stream_) {
+    return kmsr_conv3x3_winov_fwd_ex_f32(d, x, packed_w, bias, residual, out, nullptr, stream_);
+}
+
+extern "C" int kmsr_conv3x3_winov_fwd_ex_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w,
+                                             const float* bias, const float* residual, float* out, float* chan_sum,
+                                             void* stream_) {
     if (!d) return fail(KMSR_E_BADARG, "null descriptor");
+    if (d->flags & ~(uint32_t)KMSR_CONV_FLAG_RELU_MASK) return fail(KMSR_E_BADARG, "unknown conv flags 0x%x", d->flags);
+    if ((d->flags & KMSR_CONV_FLAG_RELU_MASK) && (!residual || d->relu || d->pixel_shuffle))
+        return fail(KMSR_E_BADARG, "KMSR_CONV_FLAG_RELU_MASK needs the mask tensor in `residual` and no relu / pixel_shuffle");
+    if (chan_sum && d->pixel_shuffle) return fail(KMSR_E_UNSUPPORTED, "channel sums are not produced together with pixel_shuffle");
+    if (reinterpret_cast<uintptr_t>(chan_sum) % 16) return fail(KMSR_E_BADARG, "chan_sum must be 16-byte aligned");
     if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return fail(KMSR_E_BADARG, "bad conv shape");
     if (d->stride != 1) return fail(KMSR_E_UNSUPPORTED, "winograd conv needs stride 1");
     if (d->W % 4) return fail(KMSR_E_UNSUPPORTED, "winograd-vreg conv needs W %% 4 == 0 (W=%d): rows are fetched as aligned 16-byte pieces", d->W);
@@ -472,6 +510,7 @@ extern "C" int kmsr_conv3x3_winov_fwd_f32(const kmsr_conv3x3_desc* d, const floa
     p.cgs = ceil_div(d->Cout, VCO);
     p.nchunks = ceil_div(d->Cin, VCK);
     p.relu = d->relu;
+    p.res_mask = (d->flags & KMSR_CONV_FLAG_RELU_MASK) ? 1 : 0;
     const long long nitems = (long long)p.tiles * p.cgs * d->N;
     if (nitems > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv grid too large");
     p.n_items = (int)nitems;
@@ -484,9 +523,11 @@ extern "C" int kmsr_conv3x3_winov_fwd_f32(const kmsr_conv3x3_desc* d, const floa
     const int grid = (int)std::min<long long>(nitems, cus);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (d->pixel_shuffle)
-        conv3x3_winov_kernel<true><<<grid, kThreads, 0, stream>>>(x, packed_w, bias, residual, out, p);
+        conv3x3_winov_kernel<true, false><<<grid, kThreads, 0, stream>>>(x, packed_w, bias, residual, out, nullptr, p);
+    else if (chan_sum || p.res_mask)
+        conv3x3_winov_kernel<false, true><<<grid, kThreads, 0, stream>>>(x, packed_w, bias, residual, out, chan_sum, p);
     else
-        conv3x3_winov_kernel<false><<<grid, kThreads, 0, stream>>>(x, packed_w, bias, residual, out, p);
+        conv3x3_winov_kernel<false, false><<<grid, kThreads, 0, stream>>>(x, packed_w, bias, residual, out, nullptr, p);
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
 }

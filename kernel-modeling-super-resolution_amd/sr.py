@@ -78,10 +78,12 @@ def pack_for(algo, weight):
 
 
 def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuffle=False, stride=1, out=None,
-            algo="direct"):
+            algo="direct", relu_mask=None, chan_sum=False):
     """out = epilogue(conv3x3(x, w)) with zero padding 1 (semantics: include/kmsr.h).  x [N,Cin,H,W] float32 CUDA.
     algo="direct": packed_w from pack_conv3x3_weight; "winograd" / "winograd_vreg": from pack_conv3x3_weight_wino[_vreg]
-    (pick_algo / pack_for choose and pack for a shape)."""
+    (pick_algo / pack_for choose and pack for a shape).
+    Training-step extras of the "winograd_vreg" kernel (kmsr_conv3x3_winov_fwd_ex_f32): relu_mask (out-shaped) zeroes the
+    result where relu_mask <= 0 (KMSR_CONV_FLAG_RELU_MASK); chan_sum=True returns (out, sum over (n,y,x) of out per channel)."""
     lib = L.load()
     if not (x.is_cuda and x.dtype == torch.float32 and x.ndim == 4):
         raise ValueError("x must be a 4-D float32 CUDA tensor")
@@ -93,6 +95,12 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     d = L.Conv3x3Desc()
     d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, Cin, H, W, int(cout), int(stride)
     d.relu, d.pixel_shuffle = int(bool(relu)), int(bool(pixel_shuffle))
+    if (relu_mask is not None or chan_sum) and algo != "winograd_vreg":
+        raise NotImplementedError("relu_mask / chan_sum are epilogues of the winograd_vreg kernel")
+    if relu_mask is not None:
+        assert residual is None and not relu and not pixel_shuffle
+        residual = relu_mask
+        d.flags = L.CONV_FLAG_RELU_MASK
     wino = algo in ("winograd", "winograd_vreg")
     if wino and stride != 1:
         raise NotImplementedError("winograd conv needs stride 1")
@@ -112,9 +120,18 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
         residual = residual.contiguous()
         assert tuple(residual.shape) == oshape and residual.is_cuda
     with torch.cuda.device(x.device):
+        if chan_sum:
+            part = torch.empty(lib.kmsr_conv3x3_winov_chan_sum_floats(d), device=x.device, dtype=torch.float32)
+            L.check(lib.kmsr_conv3x3_winov_fwd_ex_f32(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out),
+                                                      L.ptr(part), L.current_stream()))
+            cgs = (cout + 63) // 64                  # part[n][cg][tile][4][64] -> per-channel totals
+            return out, part.view(N, cgs, -1, 64).sum(dim=(0, 2)).reshape(-1)[:cout]
         fwd = {"direct": lib.kmsr_conv3x3_fwd_f32, "winograd": lib.kmsr_conv3x3_wino_fwd_f32,
-               "winograd_vreg": lib.kmsr_conv3x3_winov_fwd_f32}[algo]
-        L.check(fwd(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out), L.current_stream()))
+               "winograd_vreg": lib.kmsr_conv3x3_winov_fwd_ex_f32 if d.flags else lib.kmsr_conv3x3_winov_fwd_f32}[algo]
+        if algo == "winograd_vreg" and d.flags:
+            L.check(fwd(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out), None, L.current_stream()))
+        else:
+            L.check(fwd(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out), L.current_stream()))
     return out
 
 
@@ -137,19 +154,66 @@ def conv3x3_wgrad(x, dy):
     return dw
 
 
+class _TrainPacks:
+    """Packed weights of the training path, per parameter VERSION: (algo, direction) -> packed buffer, rebuilt when the
+    parameter is modified in place (optimizer step) or the entry's tensor has been freed.  Forward and data-gradient
+    launches of one step, gradient accumulation micro-steps and no-grad evaluation passes share one pack."""
+    _store = {}
+
+    @classmethod
+    def get(cls, w, algo, flip):
+        import weakref
+        key = (w.data_ptr(), tuple(w.shape), algo, flip)
+        ent = cls._store.get(key)
+        if ent is not None and ent[0] == w._version and ent[1]() is w:
+            return ent[2]
+        src = w.detach()
+        if flip:                                       # data gradient = the same convolution with w'[ci,co,u,v] = w[co,ci,2-u,2-v]
+            src = src.flip(2, 3).transpose(0, 1).contiguous()
+        packed = pack_for(algo, src)
+        if len(cls._store) > 4096:                     # parameters that went away (their storage may be reused under another key)
+            cls._store = {k: e for k, e in cls._store.items() if e[1]() is not None}
+        cls._store[key] = (w._version, weakref.ref(w), packed)
+        return packed
+
+
+def _grad_sum(g):
+    """Per-channel sum of a gradient tensor: taken from the producing launch's epilogue (tag set by _tag_sum on exactly this
+    tensor object and storage version) when there is one, else one reduction pass."""
+    tag = getattr(g, "_kmsr_chan_sum", None)
+    if tag is not None and tag[1] == g.data_ptr() and tag[2] == g._version and tag[0].numel() == g.shape[1]:
+        return tag[0]
+    return g.sum(dim=(0, 2, 3))
+
+
+def _tag_sum(t, sums):
+    t._kmsr_chan_sum = (sums, t.data_ptr(), t._version)
+    return t
+
+
 class Conv3x3Function(torch.autograd.Function):
     """y = [relu](conv3x3(x, w) + b) with the HIP kernels in both directions (stride 1):
-    forward  kmsr_conv3x3[_wino]_fwd_f32, backward  dx = conv3x3(g, flip-transposed w) (same kernels), dw =
-    kmsr_conv3x3_wgrad_f32, db = sum(g).  ReLU's mask is applied to the incoming gradient from the saved output.
+    forward  kmsr_conv3x3[_wino|_winov]_fwd_f32, backward  dx = conv3x3(g, flip-transposed w) (same kernels), dw =
+    kmsr_conv3x3_wgrad_f32, db = per-channel sum of g (from the epilogue of the launch that produced g when that was one of
+    ours).  ReLU's mask is applied to the incoming gradient from the saved output.
     Forward and data gradient take the Winograd kernel where it is eligible (F->F and F->4F layers)."""
     use_winograd = True
 
     @staticmethod
-    def _run(x, w, bias, relu, residual=None, pixel_shuffle=False):
-        cout, cin = w.shape[0], w.shape[1]
+    def _run(x, w, bias, relu, residual=None, pixel_shuffle=False, flip=False, relu_mask=None, chan_sum=False):
+        """w: the layer's [Cout,Cin,3,3] parameter; flip=True runs the data-gradient convolution (Cin <-> Cout)."""
+        cout, cin = (w.shape[1], w.shape[0]) if flip else (w.shape[0], w.shape[1])
         algo = pick_algo(cin, cout, 1, x.shape[-1], Conv3x3Function.use_winograd)
-        return conv3x3(x, pack_for(algo, w), cout, bias=bias, relu=relu, residual=residual, pixel_shuffle=pixel_shuffle,
-                       algo=algo)
+        packed = _TrainPacks.get(w, algo, flip)
+        if algo != "winograd_vreg" or pixel_shuffle:                 # epilogue extras exist in the winograd_vreg kernel only
+            if relu_mask is not None:
+                y = conv3x3(x, packed, cout, bias=bias, relu=relu, residual=residual, pixel_shuffle=pixel_shuffle, algo=algo)
+                y = torch.ops.aten.threshold_backward(y, relu_mask, 0.0)
+                return (y, y.sum(dim=(0, 2, 3))) if chan_sum else y
+            y = conv3x3(x, packed, cout, bias=bias, relu=relu, residual=residual, pixel_shuffle=pixel_shuffle, algo=algo)
+            return (y, y.sum(dim=(0, 2, 3))) if chan_sum else y
+        return conv3x3(x, packed, cout, bias=bias, relu=relu, residual=residual, pixel_shuffle=pixel_shuffle, algo=algo,
+                       relu_mask=relu_mask, chan_sum=chan_sum)
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu, residual=None, pixel_shuffle=False):
@@ -160,7 +224,7 @@ class Conv3x3Function(torch.autograd.Function):
             # the ABI rejects residual + pixel_shuffle; no layer of the SR / selector nets needs either combination
             raise ValueError("Conv3x3Function: residual cannot be combined with relu or pixel_shuffle")
         x = x.contiguous()
-        y = Conv3x3Function._run(x, weight.detach(), bias, relu, residual, pixel_shuffle)
+        y = Conv3x3Function._run(x, weight, bias, relu, residual, pixel_shuffle)
         ctx.relu = relu
         ctx.pixel_shuffle = pixel_shuffle
         ctx.has_residual = residual is not None
@@ -171,34 +235,37 @@ class Conv3x3Function(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
+        db = None
         if ctx.pixel_shuffle:
             g = torch.nn.functional.pixel_unshuffle(g, 2)     # gradient in the conv-output layout
         g = g.contiguous()
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g, y, 0.0)      # g where y > 0 else 0, one pass (no mask tensor)
-        dx = dw = db = dres = None
+        dx = dw = dres = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _grad_sum(g)
         if ctx.needs_input_grad[0]:
-            # data gradient = the same convolution with w'[ci,co,u,v] = w[co,ci,2-u,2-v]
-            dx = Conv3x3Function._run(g, weight.detach().flip(2, 3).transpose(0, 1).contiguous(), None, False)
+            # the data gradient's own per-channel sums ride along: they are the bias gradient of the layer below
+            dx, s = Conv3x3Function._run(g, weight, None, False, flip=True, chan_sum=True)
+            _tag_sum(dx, s)
         if ctx.needs_input_grad[1]:
             dw = conv3x3_wgrad(x, g)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = g.sum(dim=(0, 2, 3))
         if ctx.has_residual and ctx.needs_input_grad[4]:
             dres = g                                          # y = conv(x) + residual
         return dx, dw, db, None, dres, None
 
 
 class ResBlockFunction(torch.autograd.Function):
-    """y = h + conv2(relu(conv1(h))) as ONE autograd node (HIP kernels in both directions).  Besides the fused forward
-    epilogues this lets the backward add the skip path's gradient inside the data-gradient kernel of conv1
-    (dh = dgrad1(dt) + g as that launch's residual) instead of a separate accumulation pass per block."""
+    """y = h + conv2(relu(conv1(h))) as ONE autograd node (HIP kernels in both directions).  Backward, per block: two data-
+    gradient launches whose epilogues apply the ReLU mask (dt = dgrad2(g) where t > 0), add the skip path's gradient
+    (dh = dgrad1(dt) + g) and emit the per-channel sums that are the two bias gradients; two weight-gradient launches.
+    No elementwise or reduction pass over a feature map outside those four launches."""
 
     @staticmethod
     def forward(ctx, h, w1, b1, w2, b2):
         h = h.contiguous()
-        t = Conv3x3Function._run(h, w1.detach(), b1, True)
-        y = Conv3x3Function._run(t, w2.detach(), b2, False, residual=h)
+        t = Conv3x3Function._run(h, w1, b1, True)
+        y = Conv3x3Function._run(t, w2, b2, False, residual=h)
         ctx.save_for_backward(h, t, w1, w2)
         ctx.has_bias = (b1 is not None, b2 is not None)
         return y
@@ -206,15 +273,16 @@ class ResBlockFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         h, t, w1, w2 = ctx.saved_tensors
+        db2 = _grad_sum(g) if ctx.has_bias[1] and ctx.needs_input_grad[4] else None
         g = g.contiguous()
-        flipT = lambda w: w.detach().flip(2, 3).transpose(0, 1).contiguous()
         dw2 = conv3x3_wgrad(t, g) if ctx.needs_input_grad[3] else None
-        db2 = g.sum(dim=(0, 2, 3)) if ctx.has_bias[1] and ctx.needs_input_grad[4] else None
-        dt = Conv3x3Function._run(g, flipT(w2), None, False)
-        dt = torch.ops.aten.threshold_backward(dt, t, 0.0)
+        dt, s_dt = Conv3x3Function._run(g, w2, None, False, flip=True, relu_mask=t, chan_sum=True)
         dw1 = conv3x3_wgrad(h, dt) if ctx.needs_input_grad[1] else None
-        db1 = dt.sum(dim=(0, 2, 3)) if ctx.has_bias[0] and ctx.needs_input_grad[2] else None
-        dh = Conv3x3Function._run(dt, flipT(w1), None, False, residual=g) if ctx.needs_input_grad[0] else None
+        db1 = s_dt if ctx.has_bias[0] and ctx.needs_input_grad[2] else None
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh, s_dh = Conv3x3Function._run(dt, w1, None, False, flip=True, residual=g, chan_sum=True)
+            _tag_sum(dh, s_dh)
         return dh, dw1, db1, dw2, db2
 
 
