@@ -164,6 +164,8 @@ typedef struct kmsr_conv3x3_desc {
  * y = relu(conv(x)) computed in the gradient convolution's own epilogue (mask source = the saved y).  Honoured by
  * kmsr_conv3x3_winov_fwd[_ex]_f32; the other entry points reject it with KMSR_E_UNSUPPORTED.               */
 #define KMSR_CONV_FLAG_RELU_MASK 1u
+/* kmsr_conv3x3_wgrad_f32 only: take the direct (36 products per tap set) kernel even where the Winograd-domain one applies */
+#define KMSR_CONV_FLAG_WGRAD_DIRECT 2u
 
 /* number of floats in the packed weight buffer for (Cin, Cout) */
 size_t kmsr_conv3x3_packed_weight_floats(int32_t Cin, int32_t Cout);
@@ -198,9 +200,12 @@ int kmsr_compose_kernels_f32(const float* weights, const float* scales, int32_t 
  *   data gradient  : dx = conv3x3(dy, w')  with w'[ci,co,u,v] = w[co,ci,2-u,2-v]  -> kmsr_conv3x3_fwd_f32 on weights
  *                    packed with transpose_flip = 1 (Cin/Cout swapped in the descriptor).
  *   weight gradient: dw[co,ci,u,v] = sum_{n,y,x} dy[n,co,y,x] * x[n,ci,y+u-1,x+v-1]      (zero padded x)
- *                    fp32 MFMA, persistent workgroups accumulate 64x64x9 slabs in registers, partial slabs are
- *                    written to the workspace and summed by a second kernel in a FIXED order (bit-reproducible,
- *                    no float atomics).
+ *                    fp32 MFMA, persistent workgroups accumulate slabs in registers, partial slabs are written to the
+ *                    workspace and summed by a second kernel in a FIXED order (bit-reproducible, no float atomics).
+ *                    Even H, W % 4 == 0 with Cout > 32 are computed in the Winograd F(2x2,3x3) domain:
+ *                    dg = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G -- 16 products per (co, ci, 2x2 tile) instead of 36,
+ *                    slabs of 16 x 64 x 64; other shapes (and d->flags & KMSR_CONV_FLAG_WGRAD_DIRECT) accumulate
+ *                    64 x 64 x 9 slabs tap by tap.  Same result within fp32 rounding (tests: 2e-5 of max|dw| vs float64).
  *   bias gradient  : a plain reduction of dy; left to the caller (torch.sum).
  * d describes the FORWARD conv (N,Cin,H,W,Cout; stride must be 1; relu/pixel_shuffle ignored).
  * ========================================================================================== */

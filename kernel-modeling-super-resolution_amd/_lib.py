@@ -54,6 +54,7 @@ class ConvKDesc(C.Structure):
 
 CONVK_REFLECT, CONVK_ZERO = 0, 1
 CONV_FLAG_RELU_MASK = 1
+CONV_FLAG_WGRAD_DIRECT = 2
 
 _lib = None
 

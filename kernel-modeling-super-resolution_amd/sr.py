@@ -135,8 +135,9 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     return out
 
 
-def conv3x3_wgrad(x, dy):
-    """dw[co,ci,u,v] = sum_{n,y,x} dy[n,co,y,x] * x[n,ci,y+u-1,x+v-1]  (stride 1, zero padding 1) -> [Cout,Cin,3,3]."""
+def conv3x3_wgrad(x, dy, direct=False):
+    """dw[co,ci,u,v] = sum_{n,y,x} dy[n,co,y,x] * x[n,ci,y+u-1,x+v-1]  (stride 1, zero padding 1) -> [Cout,Cin,3,3].
+    Even H, W % 4 == 0 with Cout > 32 run in the Winograd F(2x2,3x3) domain (16 products per tile instead of 36) unless direct=True."""
     lib = L.load()
     x = x.contiguous()
     dy = dy.contiguous()
@@ -146,6 +147,7 @@ def conv3x3_wgrad(x, dy):
     Cout = dy.shape[1]
     d = L.Conv3x3Desc()
     d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, Cin, H, W, Cout, 1
+    d.flags = L.CONV_FLAG_WGRAD_DIRECT if direct else 0
     nbytes = lib.kmsr_conv3x3_wgrad_workspace_bytes(d)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     dw = torch.empty((Cout, Cin, 3, 3), device=x.device, dtype=torch.float32)

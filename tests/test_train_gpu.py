@@ -18,7 +18,10 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("N,Cin,H,W,Cout", [(2, 64, 20, 40, 64), (1, 3, 17, 33, 64), (2, 64, 16, 32, 3), (1, 64, 9, 70, 256),
                                             (3, 20, 7, 5, 12), (1, 130, 6, 34, 70),
-                                            (2, 64, 33, 45, 5), (1, 100, 5, 70, 7), (1, 8, 1, 1, 1), (2, 64, 6, 64, 20)])   # small-Cout kernels (<= 7, <= 32)
+                                            (2, 64, 33, 45, 5), (1, 100, 5, 70, 7), (1, 8, 1, 1, 1), (2, 64, 6, 64, 20),   # small-Cout kernels (<= 7, <= 32)
+                                            # even H, W % 4 == 0 and Cout > 32: the Winograd-domain kernel (partial column blocks, one tile
+                                            # row, several channel groups on either side, more stages than workgroups)
+                                            (1, 5, 2, 4, 64), (2, 64, 4, 68, 256), (1, 70, 10, 28, 40), (3, 64, 64, 96, 64), (9, 64, 128, 128, 64)])
 def test_wgrad_and_dgrad_vs_torch(N, Cin, H, W, Cout, gpu_device):
     g = torch.Generator().manual_seed(N + Cin + Cout)
     x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
@@ -29,6 +32,8 @@ def test_wgrad_and_dgrad_vs_torch(N, Cin, H, W, Cout, gpu_device):
     dw = conv3x3_wgrad(x.detach().float().cuda(), dy.float().cuda())
     assert tuple(dw.shape) == (Cout, Cin, 3, 3)
     assert _rel(dw, w.grad) < 2e-5, f"wgrad rel err {_rel(dw, w.grad):.3e}"
+    dwd = conv3x3_wgrad(x.detach().float().cuda(), dy.float().cuda(), direct=True)      # the 36-product kernel on the same shape
+    assert _rel(dwd, w.grad) < 2e-5, f"direct wgrad rel err {_rel(dwd, w.grad):.3e}"
     dx = conv3x3(dy.float().cuda(), pack_conv3x3_weight(w.detach().float().cuda(), transpose_flip=True), Cin)
     assert _rel(dx, x.grad) < 2e-5, f"dgrad rel err {_rel(dx, x.grad):.3e}"
 
