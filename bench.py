@@ -413,13 +413,15 @@ class TrainWorkload:
         self.patches_per_step = batch
         self.fwd_flops_per_patch = self.net.flops_per_lr_pixel() * h * w
         self.noise_seed = kd.rank_seed(42)       # every rank draws its own eps field (independent samples, like torch.randn_like per process)
-        # MFMA FLOPs the step ISSUES: forward and data gradient of the F->F / F->4F layers run the Winograd F(2x2,3x3)
-        # kernels (algorithmic / 2.25); head, tail and every weight gradient are direct
+        # MFMA FLOPs the step ISSUES: forward, data gradient AND weight gradient of the F->F / F->4F layers run in the Winograd
+        # F(2x2,3x3) domain (algorithmic / 2.25), as does the head's weight gradient; the head's forward and the tail's three legs
+        # are direct.  The head has no data gradient (its input is data).
         F_, Cc, nb = self.net.n_feats, C, len(self.net.body)
         wino_px = 18.0 * ((2 * nb + 1) * F_ * F_ + F_ * 4 * F_ * (1 + 4))        # per LR pixel: body + body_tail + up1 + up2(at 2x)
-        direct_px = 18.0 * (Cc * F_ + F_ * Cc * 16)                                # head + tail (at 4x)
-        self.issued_flops_per_patch = (2 * wino_px / 2.25 + wino_px + 3 * direct_px) * h * w
-        assert abs((wino_px + direct_px) * h * w - self.fwd_flops_per_patch) < 1e-6 * self.fwd_flops_per_patch
+        head_px, tail_px = 18.0 * Cc * F_, 18.0 * F_ * Cc * 16                     # head; tail (at 4x)
+        self.issued_flops_per_patch = (3 * wino_px / 2.25 + head_px * (1 + 1 / 2.25) + 3 * tail_px) * h * w
+        self.algorithmic_flops_per_patch = (3 * wino_px + 2 * head_px + 3 * tail_px) * h * w
+        assert abs((wino_px + head_px + tail_px) * h * w - self.fwd_flops_per_patch) < 1e-6 * self.fwd_flops_per_patch
 
     def step(self):
         kid = torch.randint(0, 10, (self.B,), generator=self.gen, dtype=torch.int32)     # host tensor: range-checked without a device sync
@@ -436,14 +438,15 @@ class TrainWorkload:
         self.loss = loss
 
     def roofline(self, step_ms):
-        alg = 3.0 * self.fwd_flops_per_patch * self.B / (step_ms * 1e-3) / 1e12      # fwd + dgrad + wgrad, direct-conv count
+        alg = self.algorithmic_flops_per_patch * self.B / (step_ms * 1e-3) / 1e12    # fwd + dgrad + wgrad, direct-conv count
         iss = self.issued_flops_per_patch * self.B / (step_ms * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": "whole training step (fwd + dgrad + wgrad conv3x3 kernels)", "achieved": round(iss, 2),
                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(iss / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "what": "achieved = MFMA FLOPs ISSUED per step (Winograd forward / data-gradient layers count algorithmic / 2.25, "
-                        "weight gradients and head / tail direct) / step time -- includes every non-conv pass of the step",
+                "what": "achieved = MFMA FLOPs ISSUED per step (forward, data- and weight-gradient of the F->F / F->4F layers run in the "
+                        "Winograd F(2x2,3x3) domain: algorithmic / 2.25; head forward and the tail direct) / step time -- includes "
+                        "every non-conv pass of the step",
                 "issued_flops_per_step": self.issued_flops_per_patch * self.B,
-                "algorithmic_flops_per_step": 3.0 * self.fwd_flops_per_patch * self.B,
+                "algorithmic_flops_per_step": self.algorithmic_flops_per_patch * self.B,
                 "algorithmic_tflops": round(alg, 2), "algorithmic_over_peak": round(alg / F32_MFMA_PEAK_TFLOPS, 4),
                 "step_ms": round(step_ms, 3)}
 
