@@ -324,6 +324,22 @@ int kmsr_conv3x3_bf16_pack_weights(const float* w, int32_t Cin, int32_t Cout, in
 int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x_bf16, const void* packed_w_bf16,
                           const float* bias /* [Cout] fp32 (padded) or NULL */, const void* residual_bf16,
                           void* out_bf16, void* stream);
+/* Backward legs on the same channels-last bf16 tensors; d describes the FORWARD conv (padded channel counts).
+ *   dgrad: dx[N,H,W,Cin] = conv3x3(dy[N,H,W,Cout], w') with w'[ci,co,u,v] = w[co,ci,2-u,2-v] -- the forward kernel on weights
+ *          packed by kmsr_conv3x3_bf16_pack_weights_dgrad (same fp32 master weights; needs padded Cout <= 64, i.e. not the
+ *          F->4F layers, and no pixel_shuffle: un-shuffle the gradient first).
+ *   wgrad: dw fp32 [Cout][Cin][3][3] (padded counts; rows / columns of padding channels are zero)
+ *          = sum_{n,y,x} dy * x.  Every MFMA shape needs the reduction index (pixels) contiguous per lane, which channels-last
+ *          bf16 is not, so the two operands are first expanded to fp32 planes in the workspace (exact) and the sum runs on the
+ *          fp32 weight-gradient kernels (Winograd domain where eligible): exact products of the bf16 values, fp32 accumulation,
+ *          fixed order. */
+int kmsr_conv3x3_bf16_pack_weights_dgrad(const float* w, int32_t Cin, int32_t Cout, int32_t Cin_p, int32_t Cout_p,
+                                         void* packed_bf16, void* stream);
+int kmsr_conv3x3_dgrad_bf16(const kmsr_conv3x3_desc* d, const void* dy_bf16, const void* packed_wT_bf16, void* dx_bf16,
+                            void* stream);
+size_t kmsr_conv3x3_wgrad_bf16_workspace_bytes(const kmsr_conv3x3_desc* d);
+int kmsr_conv3x3_wgrad_bf16(const kmsr_conv3x3_desc* d, const void* x_bf16, const void* dy_bf16, float* dw, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* ============================================================================================
  * Patch cutting with a water mask -- the step that FEEDS the path.

@@ -19,10 +19,11 @@ from .patches import apply_water_mask, create_patches
 from .moe import ContentAdaptiveDegradation, NoiseEstimator, SelectorNet
 from .train_moe import (PatchDiscriminator, kernel_regularization, lsgan_d_loss, lsgan_g_loss, moe_regularizer, save_moe,
                         train_moe)
-from .sr_bf16 import SRNetBF16, conv3x3_bf16, pack_conv3x3_weight_bf16, to_nhwc_bf16
+from .sr_bf16 import (Conv3x3BF16Function, SRNetBF16, conv3x3_bf16, conv3x3_dgrad_bf16, conv3x3_wgrad_bf16,
+                      pack_conv3x3_weight_bf16, pack_conv3x3_weight_bf16_dgrad, to_nhwc_bf16)
 from .sr import SRNet, conv3x3, pack_conv3x3_weight, pack_conv3x3_weight_wino, psnr
 
-__all__ = ["ConvKFunction", "convk_dgrad", "convk_forward", "convk_wgrad", "crop_patches", "kernel_metrics",
+__all__ = ["Conv3x3BF16Function", "conv3x3_dgrad_bf16", "conv3x3_wgrad_bf16", "pack_conv3x3_weight_bf16_dgrad", "ConvKFunction", "convk_dgrad", "convk_forward", "convk_wgrad", "crop_patches", "kernel_metrics",
            "kernel_regularization_single", "kernelgan_multi_step", "kernelgan_single_step", "load_full_patches",
            "load_patches_from_folder", "noise_reg_loss", "sample_patches_from_files", "train_kernelgan_multi",
            "train_kernelgan_single", "PatchDiscriminator", "kernel_regularization", "lsgan_d_loss", "lsgan_g_loss", "moe_regularizer", "save_moe", "train_moe", "denoise_band_float_nlm", "estimate_sigma", "nl_means", "apply_water_mask", "create_patches", "SRNetBF16", "conv3x3_bf16", "pack_conv3x3_weight_bf16", "to_nhwc_bf16", "DegradationModel", "process_files", "process_landsat_folder", "ConditionEncoder", "DynamicMultiBandLinearGenerator", "MultiBandLinearGenerator", "bulk_extract_kernels",

@@ -47,7 +47,9 @@ __device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-
 __device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
 
 // packed[cg][tap][co 64][Cin_p] bf16  <-  w[co][ci][tap] fp32
-__global__ void bf16_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int Cin_p, int Cout_p,
+// tf != 0: the data-gradient convolution's weights w'[ci][co][u][v] = w[co][ci][2-u][2-v] (the packed conv then maps the
+// ORIGINAL Cout channels to the original Cin channels; Cin_p / Cout_p are the padded input / output counts of THAT conv)
+__global__ void bf16_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int Cin_p, int Cout_p, int tf,
                                  unsigned short* __restrict__ packed, long long total) {
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -57,8 +59,32 @@ __global__ void bf16_pack_kernel(const float* __restrict__ w, int Cin, int Cout,
         const int cg = (int)(idx / ((long long)Cin_p * BCO * 9));
         const int cog = cg * BCO + co;
         float v = 0.f;
-        if (cog < Cout && ci < Cin) v = w[((long long)cog * Cin + ci) * 9 + tap];
+        if (tf) {
+            if (cog < Cin && ci < Cout) v = w[((long long)ci * Cin + cog) * 9 + (8 - tap)];
+        } else if (cog < Cout && ci < Cin) {
+            v = w[((long long)cog * Cin + ci) * 9 + tap];
+        }
         packed[idx] = f2bf(v);
+    }
+}
+
+// [N,H,W,Cp] bf16 (channels-last) -> [N,Cp,H,W] fp32 planes: the weight gradient's operands (K = pixels must be contiguous
+// per lane for every MFMA shape, which channels-last bf16 is not; the products of bf16 values are exact in fp32).
+// thread = one pixel, loops over the 8-channel groups of its row; a store instruction writes 64 consecutive pixels of one plane.
+__global__ void __launch_bounds__(256) nhwc_bf16_to_nchw_f32_kernel(const unsigned short* __restrict__ in, float* __restrict__ out,
+                                                                    int Cp, long long HW, long long total_px) {
+    const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (px >= total_px) return;
+    const long long n = px / HW, q = px - n * HW;
+    const u32x4* src = reinterpret_cast<const u32x4*>(in + px * Cp);
+    float* dst = out + n * Cp * HW + q;
+    for (int g = 0; g < Cp / 8; ++g) {
+        const u32x4 v = src[g];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dst[(long long)(8 * g + 2 * j) * HW] = __builtin_bit_cast(float, v[j] << 16);
+            dst[(long long)(8 * g + 2 * j + 1) * HW] = __builtin_bit_cast(float, v[j] & 0xffff0000u);
+        }
     }
 }
 
@@ -261,7 +287,20 @@ extern "C" int kmsr_conv3x3_bf16_pack_weights(const float* w, int32_t Cin, int32
         return fail(KMSR_E_BADARG, "bf16 pack: bad argument (Cin_p must be a multiple of 16 and >= Cin)");
     const long long total = (long long)kmsr_conv3x3_bf16_packed_weight_elems(Cin_p, Cout_p);
     const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-    bf16_pack_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(w, Cin, Cout, Cin_p, Cout_p,
+    bf16_pack_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(w, Cin, Cout, Cin_p, Cout_p, 0,
+                                                                          static_cast<unsigned short*>(packed), total);
+    KMSR_HIP_CHECK(hipGetLastError());
+    return KMSR_OK;
+}
+
+extern "C" int kmsr_conv3x3_bf16_pack_weights_dgrad(const float* w, int32_t Cin, int32_t Cout, int32_t Cin_p, int32_t Cout_p,
+                                                    void* packed, void* stream) {
+    // the gradient convolution reads Cout_p channels and writes Cin_p channels
+    if (!w || !packed || Cin <= 0 || Cout <= 0 || Cin_p < Cin || Cout_p < Cout || Cout_p % 16)
+        return fail(KMSR_E_BADARG, "bf16 dgrad pack: bad argument (Cout_p must be a multiple of 16 and >= Cout)");
+    const long long total = (long long)kmsr_conv3x3_bf16_packed_weight_elems(Cout_p, Cin_p);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    bf16_pack_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(w, Cin, Cout, Cout_p, Cin_p, 1,
                                                                           static_cast<unsigned short*>(packed), total);
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
@@ -314,4 +353,47 @@ extern "C" int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x, 
     if (rc != KMSR_OK) return rc;
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
+}
+
+// ---- backward legs (kmsr_conv3x3_{dgrad,wgrad}_bf16)
+extern "C" int kmsr_conv3x3_dgrad_bf16(const kmsr_conv3x3_desc* d, const void* dy, const void* packed_wT, void* dx, void* stream) {
+    if (!d) return fail(KMSR_E_BADARG, "null descriptor");
+    kmsr_conv3x3_desc g = *d;                  // the data gradient is the same convolution from Cout to Cin channels
+    g.Cin = d->Cout;
+    g.Cout = d->Cin;
+    g.relu = 0;
+    g.pixel_shuffle = 0;
+    g.flags = 0;
+    if (d->pixel_shuffle) return fail(KMSR_E_UNSUPPORTED, "bf16 dgrad: un-shuffle the gradient first (pixel_shuffle forward)");
+    return kmsr_conv3x3_fwd_bf16(&g, dy, packed_wT, nullptr, nullptr, dx, stream);
+}
+
+extern "C" size_t kmsr_conv3x3_wgrad_bf16_workspace_bytes(const kmsr_conv3x3_desc* d) {
+    if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return 0;
+    const size_t planes = (size_t)d->N * ((size_t)d->Cin + d->Cout) * d->H * d->W * sizeof(float);
+    return planes + kmsr_conv3x3_wgrad_workspace_bytes(d);
+}
+
+extern "C" int kmsr_conv3x3_wgrad_bf16(const kmsr_conv3x3_desc* d, const void* x, const void* dy, float* dw, void* workspace,
+                                       size_t workspace_bytes, void* stream_) {
+    if (!d) return fail(KMSR_E_BADARG, "null descriptor");
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return fail(KMSR_E_BADARG, "bad conv shape");
+    if (d->Cin % 8 || d->Cout % 8) return fail(KMSR_E_UNSUPPORTED, "bf16 wgrad: padded channel counts must be multiples of 8");
+    if (!x || !dy || !dw || !workspace) return fail(KMSR_E_BADARG, "null tensor pointer");
+    if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(dy) % 16) return fail(KMSR_E_BADARG, "bf16 wgrad: tensors must be 16-byte aligned");
+    const size_t need = kmsr_conv3x3_wgrad_bf16_workspace_bytes(d);
+    if (workspace_bytes < need) return fail(KMSR_E_NOMEM, "bf16 wgrad workspace %zu B < required %zu B", workspace_bytes, need);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const long long HW = (long long)d->H * d->W, total_px = (long long)d->N * HW;
+    float* xf = static_cast<float*>(workspace);
+    float* dyf = xf + (size_t)d->N * d->Cin * HW;
+    float* ws = dyf + (size_t)d->N * d->Cout * HW;
+    const unsigned blocks = (unsigned)((total_px + 255) / 256);
+    nhwc_bf16_to_nchw_f32_kernel<<<blocks, 256, 0, stream>>>(static_cast<const unsigned short*>(x), xf, d->Cin, HW, total_px);
+    nhwc_bf16_to_nchw_f32_kernel<<<blocks, 256, 0, stream>>>(static_cast<const unsigned short*>(dy), dyf, d->Cout, HW, total_px);
+    KMSR_HIP_CHECK(hipGetLastError());
+    kmsr_conv3x3_desc f = *d;
+    f.stride = 1;
+    f.flags = 0;
+    return kmsr_conv3x3_wgrad_f32(&f, xf, dyf, dw, ws, kmsr_conv3x3_wgrad_workspace_bytes(&f), stream_);
 }

@@ -59,6 +59,85 @@ def conv3x3_bf16(x, packed_w, cout_p, bias=None, relu=False, residual=None, pixe
     return out
 
 
+def pack_conv3x3_weight_bf16_dgrad(weight, cin_p, cout_p):
+    """Weights of the data-gradient conv (cout_p channels in, cin_p out): w'[ci,co,u,v] = w[co,ci,2-u,2-v], from the fp32 master."""
+    lib = L.load()
+    w = weight.detach().to(torch.float32).contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    packed = torch.empty(lib.kmsr_conv3x3_bf16_packed_weight_elems(cout_p, cin_p), device=w.device, dtype=torch.bfloat16)
+    with torch.cuda.device(w.device):
+        L.check(lib.kmsr_conv3x3_bf16_pack_weights_dgrad(L.ptr(w), Cin, Cout, cin_p, cout_p, L.ptr(packed), L.current_stream()))
+    return packed
+
+
+def _fwd_desc(x, cout_p):
+    N, H, W, cin_p = x.shape
+    d = L.Conv3x3Desc()
+    d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, cin_p, H, W, int(cout_p), 1
+    return d
+
+
+def conv3x3_dgrad_bf16(dy, packed_wT, cin_p):
+    """dy [N,H,W,cout_p] bf16 -> dx [N,H,W,cin_p] bf16  (kmsr_conv3x3_dgrad_bf16; packed_wT from pack_conv3x3_weight_bf16_dgrad)."""
+    lib = L.load()
+    assert dy.is_cuda and dy.dtype == torch.bfloat16 and dy.is_contiguous() and dy.ndim == 4
+    N, H, W, cout_p = dy.shape
+    d = L.Conv3x3Desc()
+    d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, int(cin_p), H, W, cout_p, 1
+    dx = torch.empty((N, H, W, cin_p), device=dy.device, dtype=torch.bfloat16)
+    with torch.cuda.device(dy.device):
+        L.check(lib.kmsr_conv3x3_dgrad_bf16(d, L.ptr(dy), L.ptr(packed_wT), L.ptr(dx), L.current_stream()))
+    return dx
+
+
+def conv3x3_wgrad_bf16(x, dy):
+    """x [N,H,W,cin_p], dy [N,H,W,cout_p] bf16 -> dw fp32 [cout_p, cin_p, 3, 3]  (kmsr_conv3x3_wgrad_bf16)."""
+    lib = L.load()
+    assert x.is_cuda and x.dtype == dy.dtype == torch.bfloat16 and x.is_contiguous() and dy.is_contiguous()
+    assert x.shape[:3] == dy.shape[:3]
+    d = _fwd_desc(x, dy.shape[3])
+    nbytes = lib.kmsr_conv3x3_wgrad_bf16_workspace_bytes(d)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    dw = torch.empty((dy.shape[3], x.shape[3], 3, 3), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(lib.kmsr_conv3x3_wgrad_bf16(d, L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(ws), nbytes, L.current_stream()))
+    return dw
+
+
+class Conv3x3BF16Function(torch.autograd.Function):
+    """y = [relu](conv3x3(x, w) + b) on channels-last bf16 activations [N,H,W,Cp] with fp32 master weights [Cout,Cin,3,3] / bias:
+    forward kmsr_conv3x3_fwd_bf16, backward kmsr_conv3x3_dgrad_bf16 + kmsr_conv3x3_wgrad_bf16 (fp32 weight / bias gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        cin_p, cout_p = x.shape[3], _pad16(weight.shape[0])
+        b = None
+        if bias is not None:
+            b = torch.zeros(max(cout_p, 64), device=x.device, dtype=torch.float32)
+            b[:bias.numel()] = bias.detach().float()
+        y = conv3x3_bf16(x.contiguous(), pack_conv3x3_weight_bf16(weight, cin_p, cout_p), cout_p, bias=b, relu=relu)
+        ctx.relu, ctx.has_bias = relu, bias is not None
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        cout, cin = weight.shape[0], weight.shape[1]
+        cin_p, cout_p = x.shape[3], _pad16(cout)
+        g = g.contiguous()
+        if ctx.relu:
+            g = torch.where(y > 0, g, torch.zeros_like(g))
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv3x3_dgrad_bf16(g, pack_conv3x3_weight_bf16_dgrad(weight, cin_p, cout_p), cin_p)
+        if ctx.needs_input_grad[1]:
+            dw = conv3x3_wgrad_bf16(x, g)[:cout, :cin].contiguous()
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g.float().sum(dim=(0, 1, 2))[:cout]
+        return dx, dw, db, None
+
+
 class SRNetBF16:
     """bf16 executor of an SRNet (weights are packed once from the module's fp32 parameters; call .refresh() after
     changing them)."""

@@ -78,3 +78,61 @@ def test_srnet_bf16_config4_shape(gpu_device):
     rel = float((got - want).abs().max() / want.abs().max())
     assert rel < 3e-2, f"rel err {rel:.3e}"
     assert kmsr_amd.psnr(got, want, float(want.abs().max())) > 40.0
+
+
+# ------------------------------------------------------------------ backward legs (kmsr_conv3x3_{dgrad,wgrad}_bf16)
+BWD_CASES = [  # N, Cin, H, W, Cout, relu
+    (2, 64, 20, 40, 64, True),        # body layer (Winograd-domain weight gradient on the expanded planes)
+    (1, 7, 33, 45, 64, False),        # head: 7 bands padded to 16, odd sizes (direct weight gradient)
+    (1, 64, 16, 32, 7, False),        # tail: 7 bands in a 16-channel group (Cout <= 32 kernel)
+    (2, 32, 10, 28, 48, True),
+]
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,relu", BWD_CASES)
+def test_conv3x3_bf16_backward_vs_torch(N, Cin, H, W, Cout, relu, gpu_device):
+    """Reference: float64 autograd of the conv on the bf16-ROUNDED x, w and (for the gradients) the bf16-rounded incoming
+    gradient.  dx is a bf16 tensor -> within one bf16 ulp of the reference's value (plus the fp32 accumulation error);
+    dw / db are fp32 sums of exact products -> 2e-5 of their scale."""
+    from kmsr_amd.sr_bf16 import Conv3x3BF16Function
+    g = torch.Generator().manual_seed(Cin * 11 + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    gy = torch.randn(N, Cout, H, W, generator=g)
+    cin_p, cout_p = (Cin + 15) // 16 * 16, (Cout + 15) // 16 * 16
+    xr, wr = _bf(x).double().requires_grad_(True), _bf(w).double().requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    pre = F.conv2d(xr, wr, br, padding=1)
+    ref = torch.relu(pre) if relu else pre
+    # the kernel's mask is taken from ITS bf16 output; use the same mask in the reference (outputs within one ulp of 0 differ otherwise)
+    xg = to_nhwc_bf16(x.cuda(), cin_p).requires_grad_(True)
+    wg, bg = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = Conv3x3BF16Function.apply(xg, wg, bg, relu)
+    gyb = to_nhwc_bf16(gy.cuda(), cout_p)
+    y.backward(gyb)
+    gy_ref = _bf(gy).double()
+    if relu:
+        mask = (from_nhwc(y.detach(), Cout).float().cpu() > 0).double()
+        (pre * mask).backward(gy_ref)
+    else:
+        ref.backward(gy_ref)
+    # forward sanity (one bf16 ulp)
+    yf = from_nhwc(y.detach(), Cout).float().cpu()
+    assert float(((yf - ref.detach().float()).abs() / (ref.detach().abs().float() * 2.0 ** -7 + 1e-3)).max()) <= 1.0
+    dx = from_nhwc(xg.grad, Cin).float().cpu()
+    dxr = xr.grad.float()
+    tol = dxr.abs() * 2.0 ** -7 + 2e-5 * float(dxr.abs().max())
+    assert bool(((dx - dxr).abs() <= tol).all()), f"dgrad max err {float((dx - dxr).abs().max()):.3e}"
+    assert float(xg.grad[..., Cin:].abs().max()) == 0.0 if cin_p > Cin else True           # padding channels stay zero
+    for got, want, nm in ((wg.grad.cpu(), wr.grad, "dw"), (bg.grad.cpu(), br.grad, "db")):
+        err = float((got.double() - want).abs().max() / want.abs().max())
+        assert err < 2e-5, f"{nm} rel err {err:.3e}"
+
+
+def test_bf16_backward_rejects_unsupported(gpu_device):
+    from kmsr_amd.sr_bf16 import conv3x3_dgrad_bf16, pack_conv3x3_weight_bf16_dgrad
+    w = torch.randn(256, 64, 3, 3, device="cuda")
+    dy = torch.zeros(1, 8, 32, 256, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(NotImplementedError):          # F -> 4F layer: the gradient conv would read 256 channels (kernel limit 64)
+        conv3x3_dgrad_bf16(dy, pack_conv3x3_weight_bf16_dgrad(w, 64, 256), 64)
