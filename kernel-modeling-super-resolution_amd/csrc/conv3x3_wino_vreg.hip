@@ -111,6 +111,8 @@ __device__ __forceinline__ void wait_dma() {      // all but the N newest vector
     KMSR_FENCE();
 }
 
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 struct PatchPair { f32x2 p[4]; };      // one aligned column pair of the 4 patch rows (4 ds_read_b64)
 
 template <bool PS, bool TRAIN>     // TRAIN: the training-step epilogue extras (ReLU-mask skip tensor, per-channel sums); never with PS
@@ -329,11 +331,37 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
     // Skip tensor: plain loads to registers, placed so that vmcnt (which retires in order) never makes them wait for fresh DMA
     // or for stores: channel block 0's values are requested right after the last chunk's barrier, BEFORE that chunk's DMA
     // instructions; channel block 1's after block 0's outputs are computed (its accumulators are dead) and BEFORE block 0's stores.
-    struct ItemPos { int n, cg, y0, x0, item; };
+    // Output / skip-tensor addressing of an item: buffer operations on one descriptor per (image, 64-channel group) whose record
+    // count ends at the group's last real channel, so lanes of padding channels (co >= Cout) and out-of-image lanes (sentinel offset) are dropped by
+    // the range check; a lane's byte offset for (channel block cbi, output row a) is computed once per item, registers r add
+    // r * H * W * 4 (one v_add).  (Per-element 64-bit addresses with predicates
+    // had cost ~10 VALU per store / skip load -- a third of the kernel's non-MFMA VALU, which competes with the MFMAs for issue.)
+    struct ItemPos {
+        int n, cg, y0, x0, item;
+        unsigned vo[2][2];                     // [cbi][a]
+    };
+    const unsigned HWb = (unsigned)HW * 4u;
+    constexpr unsigned OOB = 0x80000000u;
     auto item_pos = [&](int item) {
         const int tile = item % p.tiles, rest = item / p.tiles;
-        return ItemPos{rest / p.cgs, rest % p.cgs, (tile / p.tiles_x) * (2 * TROWS) + 2 * tb,
-                       (tile % p.tiles_x) * (2 * TCOLS) + 2 * (tc0 + t16), item};   // this lane's 2x2 output pixels: rows y0, y0+1, columns x0, x0+1
+        ItemPos ip{rest / p.cgs, rest % p.cgs, (tile / p.tiles_x) * (2 * TROWS) + 2 * tb,
+                   (tile % p.tiles_x) * (2 * TCOLS) + 2 * (tc0 + t16), item, {{0, 0}, {0, 0}}};   // this lane's 2x2 output pixels: rows y0, y0+1, columns x0, x0+1
+#pragma unroll
+        for (int cbi = 0; cbi < 2; ++cbi)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int co0 = (2 * hh + cbi) * 16 + 4 * kq;               // channel within the item's 64-channel group
+                const bool ok = ip.x0 < W && ip.y0 + a < H;
+                unsigned v;
+                if constexpr (PS) v = (unsigned)((((co0 >> 2) * (2 * H) + 2 * (ip.y0 + a)) * (2 * W) + 2 * ip.x0)) * 4u;   // out[n, co0/4, 2y.., 2x..]
+                else v = (unsigned)((co0 * H + ip.y0 + a) * W + ip.x0) * 4u;
+                ip.vo[cbi][a] = ok ? v : OOB;
+            }
+        return ip;
+    };
+    auto group_rsrc = [&](const float* base, const ItemPos& ip) {      // n, cg are block-uniform
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + ((long long)ip.n * p.Cout + ip.cg * VCO) * HW), 0,
+                                                 (unsigned)min(VCO, p.Cout - ip.cg * VCO) * HWb, 0x00020000);
     };
     auto row_sum16 = [&](float v) {      // sum over the 16 lanes of a DPP row (= the 16 tile columns), valid in lane 15 of the row
 #define KMSR_ROW_SHR(SH) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + SH, 0xf, 0xf, true))
@@ -344,15 +372,12 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
     auto fetch_residual = [&](const ItemPos& ip, int cbi, f32x2 (&rr)[2][4]) {
         if constexpr (!PS) {
             if (res) {                                                     // block-uniform
+                const auto rs = group_rsrc(res, ip);
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int co = ip.cg * VCO + (2 * hh + cbi) * 16 + 4 * kq + r;
-                        const bool ok = ip.x0 < W && ip.y0 + a < H && co < p.Cout;
-                        const long long o = (((long long)ip.n * p.Cout + co) * H + ip.y0 + a) * W + ip.x0;
-                        rr[a][r] = *reinterpret_cast<const f32x2*>(res + (ok ? o : 0));   // out-of-range lanes are masked at the store
-                    }
+                    for (int r = 0; r < 4; ++r)                            // out-of-range lanes read 0 and are dropped at the store
+                        rr[a][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, ip.vo[cbi][a] + (unsigned)r * HWb, 0, 0));
             }
         }
     };
@@ -380,23 +405,21 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
         for (int x = 0; x < 16; ++x) acc[cbi][x] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto store_outputs = [&](const ItemPos& ip, int cbi, const f32x2 (&Y)[2][4], const f32x2 (&rr)[2][4]) {
-        const int co0 = ip.cg * VCO + (2 * hh + cbi) * 16 + 4 * kq;
-        const bool xok = ip.x0 < W;                                        // (x0, x0+1) is an aligned pair: inside or outside as a whole
+        const auto ro = group_rsrc(out, ip);
         if constexpr (PS) {
             // conv channel q = co0 + r -> out[n, q >> 2, 2y + (r >> 1), 2x + (r & 1)]: per conv row y this lane writes the two
-            // rows 2y, 2y+1 of out channel co0 / 4, columns 2 x0 .. 2 x0 + 3
-            if (xok && co0 < p.Cout) {
-                const long long W2 = 2ll * W;
+            // rows 2y, 2y+1 of out channel co0 / 4, columns 2 x0 .. 2 x0 + 3.  The second row's offset is added in the VGPR: passing it as
+            // the instruction's SGPR soffset gave intermittently misplaced first dwords in some waves (next to LDS-DMA traffic)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    if (ip.y0 + a < H) {
-                        float* o = out + (((long long)ip.n * (p.Cout >> 2) + (co0 >> 2)) * (2ll * H) + 2 * (ip.y0 + a)) * W2 + 2 * ip.x0;
-                        *reinterpret_cast<f32x4*>(o) = f32x4{Y[a][0].x, Y[a][1].x, Y[a][0].y, Y[a][1].y};
-                        *reinterpret_cast<f32x4*>(o + W2) = f32x4{Y[a][2].x, Y[a][3].x, Y[a][2].y, Y[a][3].y};
-                    }
+            for (int a = 0; a < 2; ++a) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{Y[a][0].x, Y[a][1].x, Y[a][0].y, Y[a][1].y}), ro,
+                                                       ip.vo[cbi][a], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{Y[a][2].x, Y[a][3].x, Y[a][2].y, Y[a][3].y}), ro,
+                                                       ip.vo[cbi][a] + (unsigned)(8 * W), 0, 0);
             }
         } else {
             float cs[4] = {0.f, 0.f, 0.f, 0.f};
+            const int co0 = ip.cg * VCO + (2 * hh + cbi) * 16 + 4 * kq;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -406,9 +429,9 @@ __global__ void __launch_bounds__(kThreads, 2) conv3x3_winov_kernel(const float*
                         if (TRAIN && p.res_mask) v = f32x2{rr[a][r].x > 0.f ? v.x : 0.f, rr[a][r].y > 0.f ? v.y : 0.f};
                         else v = f32x2{v.x + rr[a][r].x, v.y + rr[a][r].y};
                     }
-                    if (xok && ip.y0 + a < H && co0 + r < p.Cout) {
-                        *reinterpret_cast<f32x2*>(out + (((long long)ip.n * p.Cout + co0 + r) * H + ip.y0 + a) * W + ip.x0) = v;
-                        if constexpr (TRAIN) cs[r] += v.x + v.y;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), ro, ip.vo[cbi][a] + (unsigned)r * HWb, 0, 0);
+                    if constexpr (TRAIN) {
+                        if (ip.vo[cbi][a] != OOB && co0 + r < p.Cout) cs[r] += v.x + v.y;
                     }
                 }
             // per-channel sums of what this wave just stored (the bias gradient of the layer that consumes this tensor as its
@@ -503,6 +526,8 @@ extern "C" int kmsr_conv3x3_winov_fwd_ex_f32(const kmsr_conv3x3_desc* d, const f
     if (!x || !packed_w || !out) return fail(KMSR_E_BADARG, "null tensor pointer");
     if (bias && d->Cout > MAX_BIAS) return fail(KMSR_E_UNSUPPORTED, "winograd-vreg conv stages the bias vector in LDS: Cout <= %d (Cout=%d)", MAX_BIAS, d->Cout);
     if ((long long)d->H * d->W * VCK >= (1ll << 31)) return fail(KMSR_E_UNSUPPORTED, "image plane exceeds 2^28 elements");
+    if ((long long)d->H * d->W * 4 * VCO >= (1ll << 31))      // 32-bit byte offsets inside one 64-channel output group
+        return fail(KMSR_E_UNSUPPORTED, "winograd-vreg conv: H*W = %lld exceeds 2^23 pixels per plane", (long long)d->H * d->W);
     WinoVParams p{};
     p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
     p.tiles_x = ceil_div(d->W, 2 * TCOLS);
