@@ -178,6 +178,15 @@ int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float
                          const float* residual,  /* out-shaped or NULL (not with pixel_shuffle)      */
                          float* out, void* stream);
 
+/* 3x3 convolution with few INPUT channels (Cin <= 8: the SR head, bands -> F, and the data gradient of the tail), stride 1,
+ * zero padding, bias / ReLU epilogue only (no residual, no pixel_shuffle, flags 0); W % 4 == 0, x 16-byte aligned.
+ * Takes the UNPACKED weights w [Cout,Cin,3,3] (they live in registers for the whole persistent kernel; for a data gradient pass
+ * w'[ci,co,u,v] = w[co,ci,2-u,2-v] made contiguous).  Same arithmetic as kmsr_conv3x3_fwd_f32 (fp32 MFMA, K ordered
+ * (tap, channel pair)); it exists because these layers are output-write bound and the general kernel's 8-channel chunks and
+ * per-tile weight reloads left them at a quarter of the HBM rate. */
+int kmsr_conv3x3_smallci_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* w, const float* bias, float* out,
+                                 void* stream);
+
 /* ============================================================================================
  * KernelGAN kernel composition (BASELINE config 5: batched per-patch kernel estimation).
  * Replaces the nested Python loops of

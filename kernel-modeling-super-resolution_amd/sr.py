@@ -63,16 +63,21 @@ def winograd_eligible(cin, cout, stride=1, width=2):
     return stride == 1 and width % 2 == 0 and cin >= 16 and cout >= 32
 
 
-def pick_algo(cin, cout, stride, width, use_winograd=True):
+def pick_algo(cin, cout, stride, width, use_winograd=True, plain=False):
     """Kernel for a stride-1 3x3 conv of this shape: the persistent LDS-DMA Winograd kernel when rows are 16-byte aligned
     (W % 4 == 0) and the bias vector fits its LDS staging (Cout <= 1024), the register-staged Winograd kernel for other even
-    widths, the direct MFMA / VALU kernels otherwise."""
+    widths, the direct MFMA / VALU kernels otherwise.  plain=True (no residual, no PixelShuffle) lets layers with <= 8 input
+    channels take the small-Cin kernel."""
+    if plain and stride == 1 and cin <= 8 and cout >= 32 and width % 4 == 0:
+        return "smallci"
     if not (use_winograd and winograd_eligible(cin, cout, stride, width)):
         return "direct"
     return "winograd_vreg" if width % 4 == 0 and cout <= 1024 else "winograd"
 
 
 def pack_for(algo, weight):
+    if algo == "smallci":                       # the small-Cin kernel reads the [Cout,Cin,3,3] tensor itself
+        return weight.detach().to(torch.float32).contiguous()
     return {"direct": pack_conv3x3_weight, "winograd": pack_conv3x3_weight_wino,
             "winograd_vreg": pack_conv3x3_weight_wino_vreg}[algo](weight)
 
@@ -88,9 +93,25 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     if not (x.is_cuda and x.dtype == torch.float32 and x.ndim == 4):
         raise ValueError("x must be a 4-D float32 CUDA tensor")
     x = x.contiguous()
-    if algo == "winograd_vreg" and x.data_ptr() % 16:
-        x = x.clone()                    # a view at an odd storage offset: the LDS-DMA kernel fetches 16-byte pieces
+    if algo in ("winograd_vreg", "smallci") and x.data_ptr() % 16:
+        x = x.clone()                    # a view at an odd storage offset: these kernels fetch 16-byte pieces
     N, Cin, H, W = x.shape
+    if algo == "smallci":
+        if residual is not None or pixel_shuffle or stride != 1 or relu_mask is not None or chan_sum:
+            raise NotImplementedError("the small-Cin kernel has a bias / ReLU epilogue only")
+        assert tuple(packed_w.shape) == (cout, Cin, 3, 3) and packed_w.is_contiguous() and packed_w.is_cuda
+        d = L.Conv3x3Desc()
+        d.N, d.Cin, d.H, d.W, d.Cout, d.stride, d.relu = N, Cin, H, W, int(cout), 1, int(bool(relu))
+        if out is None:
+            out = torch.empty((N, cout, H, W), device=x.device, dtype=torch.float32)
+        else:
+            assert tuple(out.shape) == (N, cout, H, W) and out.is_contiguous() and out.dtype == torch.float32
+        if bias is not None:
+            bias = bias.detach().contiguous()
+            assert bias.numel() == cout and bias.is_cuda
+        with torch.cuda.device(x.device):
+            L.check(lib.kmsr_conv3x3_smallci_fwd_f32(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(out), L.current_stream()))
+        return out
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     d = L.Conv3x3Desc()
     d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, Cin, H, W, int(cout), int(stride)
@@ -205,7 +226,8 @@ class Conv3x3Function(torch.autograd.Function):
     def _run(x, w, bias, relu, residual=None, pixel_shuffle=False, flip=False, relu_mask=None, chan_sum=False):
         """w: the layer's [Cout,Cin,3,3] parameter; flip=True runs the data-gradient convolution (Cin <-> Cout)."""
         cout, cin = (w.shape[1], w.shape[0]) if flip else (w.shape[0], w.shape[1])
-        algo = pick_algo(cin, cout, 1, x.shape[-1], Conv3x3Function.use_winograd)
+        algo = pick_algo(cin, cout, 1, x.shape[-1], Conv3x3Function.use_winograd,
+                         plain=residual is None and not pixel_shuffle and relu_mask is None)
         packed = _TrainPacks.get(w, algo, flip)
         if algo != "winograd_vreg" or pixel_shuffle:                 # epilogue extras exist in the winograd_vreg kernel only
             if relu_mask is not None:
@@ -464,7 +486,8 @@ class SRNet(nn.Module):
         return c.get(conv, algo)
 
     def _conv(self, name, conv, x, **kw):
-        algo = pick_algo(conv.in_channels, conv.out_channels, 1, x.shape[-1], self.use_winograd)
+        algo = pick_algo(conv.in_channels, conv.out_channels, 1, x.shape[-1], self.use_winograd,
+                         plain=kw.get("residual") is None and not kw.get("pixel_shuffle"))
         return conv3x3(x, self._packed(name, conv, algo), conv.out_channels, bias=conv.bias, algo=algo, **kw)
 
     def forward(self, x):

@@ -130,6 +130,33 @@ def test_conv3x3_winograd_vreg_vs_torch(N, Cin, H, W, Cout, bias, relu, res, ps,
         conv3x3(torch.zeros(1, Cin, 4, 6, device=gpu_device), pack_for(algo, w.cuda()), Cout, algo=algo)
 
 
+SMALLCI_CASES = [  # N, Cin, H, W, Cout, bias, relu
+    (2, 3, 24, 40, 64, True, False),        # the SR head (3 bands), partial column tile
+    (1, 5, 17, 132, 64, True, True),        # 5 bands (padded to 3 channel pairs), odd height, 3 column tiles
+    (2, 8, 9, 68, 128, False, False),       # 4 channel pairs, two cout groups (weights reloaded when the group changes)
+    (1, 7, 16, 64, 70, True, False),        # Cout not a multiple of 64: channels past Cout dropped by the range check
+    (3, 1, 8, 8, 32, True, True),           # one input channel, one 32-channel block, tile larger than the image
+    (1, 5, 200, 256, 64, True, False),      # more items than persistent workgroups would get on a small grid
+]
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,bias,relu", SMALLCI_CASES)
+def test_conv3x3_small_cin_vs_torch(N, Cin, H, W, Cout, bias, relu, gpu_device):
+    """kmsr_conv3x3_smallci_fwd_f32 (weights in registers, K = (tap, channel pair)): same tolerance as the general direct kernel."""
+    from kmsr_amd.sr import pack_for, pick_algo
+    assert pick_algo(Cin, Cout, 1, W, plain=True) == "smallci" and pick_algo(Cin, Cout, 1, W) != "smallci"
+    g = torch.Generator().manual_seed(13 * N + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g) if bias else None
+    out = conv3x3(x.cuda(), pack_for("smallci", w.cuda()), Cout, bias=None if b is None else b.cuda(), relu=relu, algo="smallci")
+    _check(out, _ref_conv(x, w, b, relu, None, False), tol=1e-5, what=f"smallci {Cin}->{Cout} {H}x{W}")
+    with pytest.raises(NotImplementedError):
+        conv3x3(x.cuda(), pack_for("smallci", w.cuda()), Cout, residual=out, algo="smallci")
+    with pytest.raises(NotImplementedError):            # W % 4 != 0
+        conv3x3(torch.zeros(1, Cin, 4, 6, device=gpu_device), pack_for("smallci", w.cuda()), Cout, algo="smallci")
+
+
 def test_conv3x3_tap_orientation_and_channel_map(gpu_device):
     """A = permutation check with asymmetric data: w[co,ci,u,v] = 1 iff ci == perm[co] and (u,v) == shift[co].
     Every output channel must equal ONE input channel shifted by one specific tap -- catches transposed taps
