@@ -324,11 +324,12 @@ __global__ void __launch_bounds__(256) conv3x3_smallco_kernel(const float* __res
         }
     };
 
-    float acc[COUT][4];
+    // Accumulators as packed pairs of adjacent pixels: v_pk_fma_f32 issues two FMAs per slot with the (wave-uniform) weight
+    // broadcast from its SGPR -- this layer is VALU-bound (2 * 9 * Cin * COUT flops per output pixel on the vector pipe).
+    // Pixel pairs at odd tap offsets are read as their own aligned register pairs (ds_read2_b32), not shuffled.
+    f32x2 acc[COUT][2];
 #pragma unroll
-    for (int co = 0; co < COUT; ++co)
-#pragma unroll
-        for (int px = 0; px < 4; ++px) acc[co][px] = 0.f;
+    for (int co = 0; co < COUT; ++co) acc[co][0] = acc[co][1] = f32x2{0.f, 0.f};
 
     const int nchunks = (p.Cin + SCK - 1) / SCK;
     load_chunk(0);
@@ -339,21 +340,24 @@ __global__ void __launch_bounds__(256) conv3x3_smallco_kernel(const float* __res
         if (chunk + 1 < nchunks) load_chunk(chunk + 1);
         const float* inb = lds + b * IN_FLOATS + ty * SIWP + 4 * tx;
         const float* __restrict__ wc = wpk + (long long)chunk * SCK * 9 * COUT;   // wave-uniform
-#pragma unroll 1   // keep one channel's 18 LDS values live at a time: ~100 VGPRs -> 4 waves/SIMD instead of 2
+#pragma unroll 1   // keep one channel's LDS values live at a time: ~100 VGPRs -> 4 waves/SIMD instead of 2
         for (int c = 0; c < SCK; ++c) {
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const float* rowp = inb + (c * SIH + dy) * SIWP;
                 const f32x4 a = *reinterpret_cast<const f32x4*>(rowp);
-                const f32x2 bb = *reinterpret_cast<const f32x2*>(rowp + 4);
-                const float v[6] = {a.x, a.y, a.z, a.w, bb.x, bb.y};
+                const f32x2 v45 = *reinterpret_cast<const f32x2*>(rowp + 4);
+                const f32x2 v12 = f32x2{rowp[1], rowp[2]}, v34 = f32x2{rowp[3], rowp[4]};
+                const f32x2 pa[3] = {f32x2{a.x, a.y}, v12, f32x2{a.z, a.w}};
+                const f32x2 pb[3] = {f32x2{a.z, a.w}, v34, v45};
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
                     for (int co = 0; co < COUT; ++co) {
                         const float wv = wc[(c * 9 + dy * 3 + dx) * COUT + co];
-#pragma unroll
-                        for (int px = 0; px < 4; ++px) acc[co][px] = fmaf(wv, v[px + dx], acc[co][px]);
+                        const f32x2 w2 = f32x2{wv, wv};
+                        acc[co][0] = __builtin_elementwise_fma(w2, pa[dx], acc[co][0]);
+                        acc[co][1] = __builtin_elementwise_fma(w2, pb[dx], acc[co][1]);
                     }
                 }
             }
@@ -371,7 +375,7 @@ __global__ void __launch_bounds__(256) conv3x3_smallco_kernel(const float* __res
             float v[4];
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
-                v[px] = acc[co][px] + bv;
+                v[px] = acc[co][px >> 1][px & 1] + bv;
                 if (p.relu) v[px] = fmaxf(v[px], 0.f);
             }
             if (x + 3 < p.Wo && (p.Wo & 3) == 0) {

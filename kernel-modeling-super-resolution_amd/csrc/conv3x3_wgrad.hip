@@ -17,6 +17,7 @@ namespace kmsr {
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4v = __attribute__((ext_vector_type(4))) float;
 
 constexpr int WR = 2, WC = 32;            // pixel stage: rows x cols
 constexpr int WPX = WR * WC;              // 64 pixels per stage
@@ -222,27 +223,37 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_smallco_kernel(const flo
     const int total = p.N * p.n_stages;
     const int ci_left = p.Cin - cig * 64;
 
-    // staging maps: x: thread = (px = tid & 63, sub = wave id) -> channels 4 q + sub, q < 16;
-    //               dy halo: element e = tid + 256 j -> (pos = e / Cout, co = e % Cout), e < 136 * Cout (<= 952 -> 4 loads)
+    // staging maps (buffer loads: the range check supplies the zero padding and the channel tail):
+    //   x : 16-byte pieces when W % 4 == 0: e = tid + 256 j, j < 4 -> piece e & 7 (columns 4 piece .. +3), row (e >> 3) & 1, channel e >> 4;
+    //       dword loads otherwise: thread = (px = tid & 63, sub = wave id) -> channels 4 q + sub, q < 16
+    //   dy halo: element e = tid + 256 j -> (pos = e / Cout, co = e % Cout), e < 136 * Cout (<= 952 -> 4 loads)
     const int dpx = tid & 63, sub = wv, dr = dpx / WC, dc = dpx % WC;
+    const int xq = tid & 7, xrow = (tid >> 3) & 1, xch = tid >> 4;
     constexpr int NDYL = (SD_POS * 7 + 255) / 256;
+    const unsigned HWb = (unsigned)HW * 4u;
+    constexpr unsigned OOB = 0x80000000u;
+    const bool wide = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(xg) & 15) == 0;       // block-uniform
     float xr[16], dyr[NDYL];
     auto load_stage = [&](int s) {
         const int n = s / p.n_stages, t = s % p.n_stages;
         const int y0 = (t / p.tiles_x) * WR, x0 = (t % p.tiles_x) * WC;
-        const float* __restrict__ xn = xg + ((long long)n * p.Cin + cig * 64) * HW;
-        const float* __restrict__ dyn = dyg + (long long)n * Cout * HW;
-        {
-            const int y = y0 + dr, x = x0 + dc;
-            const bool pok = y < H && x < W;
-            const long long poff = pok ? (long long)y * W + x : 0;
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xg + ((long long)n * p.Cin + cig * 64) * HW), 0,
+                                                          (unsigned)min(ci_left, 64) * HWb, 0x00020000);
+        const auto rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dyg + (long long)n * Cout * HW), 0, (unsigned)Cout * HWb, 0x00020000);
+        if (wide) {
+            const int y = y0 + xrow, x = x0 + 4 * xq;
+            const unsigned vo = ((y < H && x < W) ? (unsigned)(y * W + x) * 4u : OOB) + (unsigned)xch * HWb;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int ci = 4 * q + sub;
-                const bool ok = pok && ci < ci_left;
-                const float v = xn[ok ? ci * HW + poff : 0];
-                xr[q] = ok ? v : 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + (unsigned)(16 * j) * HWb, 0, 0));
+                xr[4 * j + 0] = v.x; xr[4 * j + 1] = v.y; xr[4 * j + 2] = v.z; xr[4 * j + 3] = v.w;
             }
+        } else {
+            const int y = y0 + dr, x = x0 + dc;
+            const unsigned vo = (y < H && x < W) ? (unsigned)(y * W + x) * 4u : OOB;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                xr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo + (unsigned)(4 * q + sub) * HWb, 0, 0));
         }
 #pragma unroll
         for (int j = 0; j < NDYL; ++j) {
@@ -250,15 +261,21 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_smallco_kernel(const flo
             const int pos = e / Cout, co = e - pos * Cout;
             const int y = y0 - 1 + pos / SD_COLS, x = x0 - 1 + pos % SD_COLS;
             const bool ok = e < SD_POS * Cout && y >= 0 && y < H && x >= 0 && x < W;
-            const float v = dyn[ok ? co * HW + (long long)y * W + x : 0];
-            dyr[j] = ok ? v : 0.f;
+            dyr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, ok ? (unsigned)(y * W + x) * 4u + (unsigned)co * HWb : OOB, 0, 0));
         }
     };
     auto store_stage = [&](int b) {
         float* xl = lds + b * SS_F;
         float* dl = xl + SX_F;
+        if (wide) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) xl[dpx * PCH + 4 * q + sub] = xr[q];        // [px][ci]
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xl[(xrow * WC + 4 * xq + k) * PCH + xch + 16 * j] = xr[4 * j + k];     // [px][ci]: banks (px + ci) mod 64, all distinct
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xl[dpx * PCH + 4 * q + sub] = xr[q];    // [px][ci]
+        }
 #pragma unroll
         for (int j = 0; j < NDYL; ++j) {
             const int e = tid + 256 * j;
