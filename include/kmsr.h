@@ -178,6 +178,13 @@ int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float
                          const float* residual,  /* out-shaped or NULL (not with pixel_shuffle)      */
                          float* out, void* stream);
 
+/* Backward of the fused PixelShuffle(2) store: g [N,C,2H,2W] (gradient in the shuffled layout) -> gu [N,4C,H,W] with
+ * gu[n,4c+2i+j,y,x] = g[n,c,2y+i,2x+j], plus per-channel partial sums partials[N * ceil(H/32)][4C] (add them over the first
+ * axis for the bias gradient sum_{n,y,x} gu; fixed order).  One pass instead of permute-copy + reduction.  W % 4 == 0. */
+size_t kmsr_pixel_unshuffle2_sum_partials(int32_t N, int32_t C, int32_t H);    /* number of floats in `partials` */
+int kmsr_pixel_unshuffle2_sum_f32(const float* g, int32_t N, int32_t C, int32_t H, int32_t W, float* gu, float* partials,
+                                  void* stream);
+
 /* 3x3 convolution with few INPUT channels (Cin <= 8: the SR head, bands -> F, and the data gradient of the tail), stride 1,
  * zero padding, bias / ReLU epilogue only (no residual, no pixel_shuffle, flags 0); W % 4 == 0, x 16-byte aligned.
  * Takes the UNPACKED weights w [Cout,Cin,3,3] (they live in registers for the whole persistent kernel; for a data gradient pass

@@ -200,6 +200,22 @@ class _TrainPacks:
         return packed
 
 
+def pixel_unshuffle2_sum(g):
+    """g [N,C,2H,2W] -> (gu [N,4C,H,W], per-channel sums [4C]) in one pass (kmsr_pixel_unshuffle2_sum_f32)."""
+    lib = L.load()
+    g = g.contiguous()
+    N, C, H2, W2 = g.shape
+    H, W = H2 // 2, W2 // 2
+    if W % 4 or g.data_ptr() % 16 or not g.is_cuda or g.dtype != torch.float32:
+        gu = torch.nn.functional.pixel_unshuffle(g, 2).contiguous()
+        return gu, gu.sum(dim=(0, 2, 3))
+    gu = torch.empty((N, 4 * C, H, W), device=g.device, dtype=torch.float32)
+    part = torch.empty(lib.kmsr_pixel_unshuffle2_sum_partials(N, C, H), device=g.device, dtype=torch.float32)
+    with torch.cuda.device(g.device):
+        L.check(lib.kmsr_pixel_unshuffle2_sum_f32(L.ptr(g), N, C, H, W, L.ptr(gu), L.ptr(part), L.current_stream()))
+    return gu, part.view(-1, 4 * C).sum(dim=0)
+
+
 def _grad_sum(g):
     """Per-channel sum of a gradient tensor: taken from the producing launch's epilogue (tag set by _tag_sum on exactly this
     tensor object and storage version) when there is one, else one reduction pass."""
@@ -261,7 +277,8 @@ class Conv3x3Function(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         db = None
         if ctx.pixel_shuffle:
-            g = torch.nn.functional.pixel_unshuffle(g, 2)     # gradient in the conv-output layout
+            g, s = pixel_unshuffle2_sum(g)                    # gradient in the conv-output layout + its channel sums, one pass
+            _tag_sum(g, s)
         g = g.contiguous()
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g, y, 0.0)      # g where y > 0 else 0, one pass (no mask tensor)

@@ -104,3 +104,18 @@ def test_srnet_training_step_matches_oracle(gpu_device):
     # the inference path picks up the updated weights (pack cache keyed on the parameter version)
     with torch.no_grad():
         assert _rel(net(lr_img.cuda()), ref(lr_img)) < 1e-4
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 3, 6, 8), (1, 64, 40, 36), (3, 5, 33, 4), (1, 2, 5, 6)])
+def test_pixel_unshuffle2_sum_vs_torch(N, C, H, W, gpu_device):
+    """kmsr_pixel_unshuffle2_sum_f32 (backward of the fused PixelShuffle store): the permutation is exact, the channel sums are
+    fp32 sums in a fixed order (run-to-run identical); W % 4 != 0 takes the torch path."""
+    from kmsr_amd.sr import pixel_unshuffle2_sum
+    g = torch.randn(N, C, 2 * H, 2 * W, generator=torch.Generator().manual_seed(N + C + H)).cuda()
+    gu, s = pixel_unshuffle2_sum(g)
+    ref = F.pixel_unshuffle(g, 2)
+    assert torch.equal(gu, ref)
+    want = ref.double().sum(dim=(0, 2, 3))
+    assert float((s.double() - want).abs().max()) <= 2e-6 * float(ref.abs().double().sum(dim=(0, 2, 3)).max())
+    gu2, s2 = pixel_unshuffle2_sum(g)
+    assert torch.equal(s, s2)
