@@ -226,7 +226,8 @@ def _grad_sum(g):
 
 
 def _tag_sum(t, sums):
-    t._kmsr_chan_sum = (sums, t.data_ptr(), t._version)
+    if sums is not None:
+        t._kmsr_chan_sum = (sums, t.data_ptr(), t._version)
     return t
 
 
@@ -246,12 +247,11 @@ class Conv3x3Function(torch.autograd.Function):
                          plain=residual is None and not pixel_shuffle and relu_mask is None)
         packed = _TrainPacks.get(w, algo, flip)
         if algo != "winograd_vreg" or pixel_shuffle:                 # epilogue extras exist in the winograd_vreg kernel only
-            if relu_mask is not None:
-                y = conv3x3(x, packed, cout, bias=bias, relu=relu, residual=residual, pixel_shuffle=pixel_shuffle, algo=algo)
-                y = torch.ops.aten.threshold_backward(y, relu_mask, 0.0)
-                return (y, y.sum(dim=(0, 2, 3))) if chan_sum else y
+            # no fused sums here: (y, None) -- whoever needs the sums of y reduces it then (often nobody does)
             y = conv3x3(x, packed, cout, bias=bias, relu=relu, residual=residual, pixel_shuffle=pixel_shuffle, algo=algo)
-            return (y, y.sum(dim=(0, 2, 3))) if chan_sum else y
+            if relu_mask is not None:
+                y = torch.ops.aten.threshold_backward(y, relu_mask, 0.0)
+            return (y, None) if chan_sum else y
         return conv3x3(x, packed, cout, bias=bias, relu=relu, residual=residual, pixel_shuffle=pixel_shuffle, algo=algo,
                        relu_mask=relu_mask, chan_sum=chan_sum)
 
@@ -319,7 +319,7 @@ class ResBlockFunction(torch.autograd.Function):
         dw2 = conv3x3_wgrad(t, g) if ctx.needs_input_grad[3] else None
         dt, s_dt = Conv3x3Function._run(g, w2, None, False, flip=True, relu_mask=t, chan_sum=True)
         dw1 = conv3x3_wgrad(h, dt) if ctx.needs_input_grad[1] else None
-        db1 = s_dt if ctx.has_bias[0] and ctx.needs_input_grad[2] else None
+        db1 = (s_dt if s_dt is not None else dt.sum(dim=(0, 2, 3))) if ctx.has_bias[0] and ctx.needs_input_grad[2] else None
         dh = None
         if ctx.needs_input_grad[0]:
             dh, s_dh = Conv3x3Function._run(dt, w1, None, False, flip=True, residual=g, chan_sum=True)
