@@ -225,6 +225,14 @@ int kmsr_compose_kernels_f32(const float* weights, const float* scales, int32_t 
  *   bias gradient  : a plain reduction of dy; left to the caller (torch.sum).
  * d describes the FORWARD conv (N,Cin,H,W,Cout; stride must be 1; relu/pixel_shuffle ignored).
  * ========================================================================================== */
+/* Named forms of two legs (SURVEY 8b's export list); both are kmsr_conv3x3_fwd_f32 with the descriptor rewritten:
+ *   dgrad: d describes the FORWARD conv; packed_wT = kmsr_conv3x3_pack_weights_f32(w, Cin, Cout, transpose_flip = 1);
+ *          dy [N,Cout,H,W] -> dx [N,Cin,H,W].  (The Winograd kernels serve the same purpose with their own packs: pack
+ *          w' = flip(w).transpose(0,1) with kmsr_conv3x3_winov_pack_weights_f32 and call kmsr_conv3x3_winov_fwd[_ex]_f32.)
+ *   pixelshuffle_fwd: d->pixel_shuffle forced to 1 (conv + PixelShuffle(2) in the store). */
+int kmsr_conv3x3_dgrad_f32(const kmsr_conv3x3_desc* d, const float* dy, const float* packed_wT, float* dx, void* stream);
+int kmsr_conv3x3_pixelshuffle_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
+                                      float* out, void* stream);
 size_t kmsr_conv3x3_wgrad_workspace_bytes(const kmsr_conv3x3_desc* d);
 int kmsr_conv3x3_wgrad_f32(const kmsr_conv3x3_desc* d, const float* x, const float* dy, float* dw /* [Cout,Cin,3,3] */,
                            void* workspace, size_t workspace_bytes, void* stream);
@@ -340,6 +348,8 @@ int kmsr_conv3x3_bf16_pack_weights(const float* w, int32_t Cin, int32_t Cout, in
 int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x_bf16, const void* packed_w_bf16,
                           const float* bias /* [Cout] fp32 (padded) or NULL */, const void* residual_bf16,
                           void* out_bf16, void* stream);
+int kmsr_conv3x3_pixelshuffle_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x_bf16, const void* packed_w_bf16, const float* bias,
+                                       void* out_bf16, void* stream);   /* kmsr_conv3x3_fwd_bf16 with pixel_shuffle = 1 */
 /* Backward legs on the same channels-last bf16 tensors; d describes the FORWARD conv (padded channel counts).
  *   dgrad: dx[N,H,W,Cin] = conv3x3(dy[N,H,W,Cout], w') with w'[ci,co,u,v] = w[co,ci,2-u,2-v] -- the forward kernel on weights
  *          packed by kmsr_conv3x3_bf16_pack_weights_dgrad (same fp32 master weights; needs padded Cout <= 64, i.e. not the

@@ -77,6 +77,9 @@ SYMBOLS = {
     "kmsr_conv3x3_fwd_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "kmsr_pixel_unshuffle2_sum_partials": (_sz, [_i32, _i32, _i32]),
     "kmsr_pixel_unshuffle2_sum_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "kmsr_conv3x3_dgrad_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp]),
+    "kmsr_conv3x3_pixelshuffle_fwd_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp]),
+    "kmsr_conv3x3_pixelshuffle_fwd_bf16": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp]),
     "kmsr_conv3x3_smallci_fwd_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp]),
     "kmsr_conv3x3_wgrad_workspace_bytes": (_sz, [C.POINTER(Conv3x3Desc)]),
     "kmsr_conv3x3_wgrad_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _sz, _vp]),

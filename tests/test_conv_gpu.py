@@ -338,3 +338,29 @@ def test_srnet_fused_upsampler_follows_weight_updates(gpu_device):
         net.tail.bias.mul_(2.0)
     y1 = net(x)
     assert torch.allclose(y1, 2 * y0, rtol=1e-4, atol=1e-5)
+
+
+def test_named_dgrad_and_pixelshuffle_entry_points(gpu_device):
+    """kmsr_conv3x3_dgrad_f32 / kmsr_conv3x3_pixelshuffle_fwd_f32 (SURVEY 8b's export names) against torch autograd / PixelShuffle."""
+    import ctypes as C
+    from kmsr_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(2)
+    N, Cin, H, W, Cout = 2, 24, 12, 20, 40
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g, dtype=torch.float64) / 15).requires_grad_()
+    dy = torch.randn(N, Cout, H, W, generator=g, dtype=torch.float64)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    d = L.Conv3x3Desc()
+    d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, Cin, H, W, Cout, 1
+    wT = pack_conv3x3_weight(w.detach().float().cuda(), transpose_flip=True)
+    dyg = dy.float().cuda()
+    dx = torch.empty(N, Cin, H, W, device="cuda")
+    L.check(lib.kmsr_conv3x3_dgrad_f32(d, L.ptr(dyg), L.ptr(wT), L.ptr(dx), L.current_stream()))
+    assert float((dx.cpu().double() - x.grad).abs().max() / x.grad.abs().max()) < 2e-5
+    pw = pack_conv3x3_weight(w.detach().float().cuda())
+    xg = x.detach().float().cuda()
+    out = torch.empty(N, Cout // 4, 2 * H, 2 * W, device="cuda")
+    L.check(lib.kmsr_conv3x3_pixelshuffle_fwd_f32(d, L.ptr(xg), L.ptr(pw), None, L.ptr(out), L.current_stream()))
+    ref = F.pixel_shuffle(F.conv2d(x.detach(), w.detach(), None, padding=1), 2)
+    assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-5
