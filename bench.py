@@ -235,12 +235,13 @@ class DegradeSRWorkload:
 
     def issued_mfma_flops_per_step(self, fused):
         """MFMA FLOPs one step issues (the degradation and the 64->3 tail are VALU kernels and not counted):
-        Winograd layers = algorithmic / 2.25; head = direct MFMA with the 3 bands padded to one 8-channel chunk;
-        collapsed upsampler = one 5x5 conv 64 -> 48 (padded to 64) per LR pixel (+ the frame strips, < 2 % of it, not counted)."""
+        Winograd layers = algorithmic / 2.25; head = small-Cin MFMA kernel with the 3 bands padded to 2 channel pairs;
+        collapsed upsampler = one 5x5 conv 64 -> 48 per LR pixel (32x32x2 tiles for 32 channels + 16x16x4 tiles for 16: no channel
+        padding; + the frame strips, < 2 % of it, not counted)."""
         px = self.B * self.h * self.w
         body = 33 * 18.0 * 64 * 64 / 2.25
-        head = 18.0 * 8 * 64
-        up = 50.0 * 64 * 64 if fused else 18.0 * 64 * 256 * (1 + 4) / 2.25
+        head = 18.0 * 4 * 64
+        up = 50.0 * 64 * 16 * self.C if fused else 18.0 * 64 * 256 * (1 + 4) / 2.25
         return (body + head + up) * px
 
     def roofline_degrade(self):

@@ -38,6 +38,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 struct UpParams {
     int N, Cin, H, W, Cout;
     int tiles_x, tiles, cgs, nchunks, n_blocks;
+    int cg0;                              // first cout group of this launch (the launch covers groups cg0 .. cg0 + cgs - 1)
 };
 
 // packed[cg][chunk][tap][c][co] <- w[co_g][ci_g][tap]  (zero padded)
@@ -55,6 +56,10 @@ __global__ void pack5_kernel(const float* __restrict__ w, int Cin, int Cout, flo
     }
 }
 
+// N32 full 32-channel blocks (32x32x2 MFMA tiles) + REM * 16 channels (16x16x4 tiles) of real output channels in the cout groups
+// of this launch: <2,0> = 64, <1,1> = 48 (3 bands), <1,0> = 32, <0,1> = 16 (the second group of 5 bands).  A half-empty 32-row
+// block would spend 64-cycle MFMAs on zero rows; the 16-row remainder costs 4 x 32 cycles per tap instead of 4 x 64.
+template <int N32, int REM>
 __global__ void __launch_bounds__(256, 2) conv5x5_ps4_kernel(const float* __restrict__ xg, const float* __restrict__ wpk,
                                                              const float* __restrict__ bias, float* __restrict__ out,
                                                              UpParams p) {
@@ -68,9 +73,10 @@ __global__ void __launch_bounds__(256, 2) conv5x5_ps4_kernel(const float* __rest
     int bid = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (blockIdx.x >> 3);
     const int tile = bid % p.tiles;
     bid /= p.tiles;
-    const int cg = bid % p.cgs;
+    const int cg = p.cg0 + bid % p.cgs;
     const int n = bid / p.cgs;
     const int ty0 = (tile / p.tiles_x) * UTH, tx0 = (tile % p.tiles_x) * UTW;
+    const int l16 = lane & 15, kq = lane >> 4;
     const int H = p.H, W = p.W;
     const long long HW = (long long)H * W;
 
@@ -121,16 +127,22 @@ __global__ void __launch_bounds__(256, 2) conv5x5_ps4_kernel(const float* __rest
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[N32 > 0 ? N32 : 1][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < N32; ++m)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+    f32x4 racc[2][2];                                                 // remainder tiles [px row nt][column half]: 16 channels x 16 pixels
+#pragma unroll
+    for (int q = 0; q < 2; ++q) racc[q][0] = racc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int aoff = half * UCOB + l32;                               // + (tap*UCK + 2*kp)*UCOB + 32*mt
     const int boff = half * (UIH * UIWP) + (2 * wv) * UIWP + l32;     // + (2*kp)*UIH*UIWP + (nt + dy)*UIWP + dx
+    // remainder (v_mfma_f32_16x16x4_f32): A lane = (channel 32 N32 + l16, input channel kq), B lane = (input channel kq, pixel l16)
+    const int raoff = kq * UCOB + 32 * N32 + l16;                     // + tap*UCK*UCOB
+    const int rboff = kq * (UIH * UIWP) + (2 * wv) * UIWP + l16;      // + (nt + dy)*UIWP + dx + 16*ph
 
     const int nch = p.nchunks;
     load_chunk(0);
@@ -146,16 +158,28 @@ __global__ void __launch_bounds__(256, 2) conv5x5_ps4_kernel(const float* __rest
             const int dy = tap / UK, dx = tap % UK;
             if (tap == kUFetchTap && more) load_chunk(chunk + 1);
             if (tap == kURestageTap && more) store_chunk(b ^ 1);   // the other buffer was last read before the previous barrier
+            if constexpr (N32 > 0) {
 #pragma unroll
-            for (int kp = 0; kp < UCK / 2; ++kp) {
-                const float a0 = wb[aoff + (tap * UCK + 2 * kp) * UCOB];
-                const float a1 = wb[aoff + (tap * UCK + 2 * kp) * UCOB + 32];
-                const float b0 = inb[boff + (2 * kp) * (UIH * UIWP) + dy * UIWP + dx];
-                const float b1 = inb[boff + (2 * kp) * (UIH * UIWP) + (1 + dy) * UIWP + dx];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                for (int kp = 0; kp < UCK / 2; ++kp) {
+                    const float b0 = inb[boff + (2 * kp) * (UIH * UIWP) + dy * UIWP + dx];
+                    const float b1 = inb[boff + (2 * kp) * (UIH * UIWP) + (1 + dy) * UIWP + dx];
+#pragma unroll
+                    for (int mt = 0; mt < N32; ++mt) {
+                        const float a = wb[aoff + (tap * UCK + 2 * kp) * UCOB + 32 * mt];
+                        acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[mt][0], 0, 0, 0);
+                        acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[mt][1], 0, 0, 0);
+                    }
+                }
+            }
+            if constexpr (REM) {                                      // all UCK = 4 input channels in one K = 4 step
+                const float ra = wb[raoff + tap * UCK * UCOB];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph) {
+                        const float rb = inb[rboff + (nt + dy) * UIWP + dx + 16 * ph];
+                        racc[nt][ph] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra, rb, racc[nt][ph], 0, 0, 0);
+                    }
             }
         }
         __syncthreads();
@@ -173,7 +197,7 @@ __global__ void __launch_bounds__(256, 2) conv5x5_ps4_kernel(const float* __rest
     const long long W4 = 4ll * W, H4 = 4ll * H;
     const int bands = p.Cout >> 4;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < N32; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int y = ty0 + 2 * wv + nt;
@@ -192,6 +216,21 @@ __global__ void __launch_bounds__(256, 2) conv5x5_ps4_kernel(const float* __rest
                 }
             }
         }
+    }
+    if constexpr (REM) {       // D lane holds channels 32 N32 + 4 kq + r (r = sub-pixel column b), pixel l16 of its 16-pixel half row
+        const int col = 32 * N32 + 4 * kq, co0 = cg * UCOB + col;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + col);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const int y = ty0 + 2 * wv + nt, xx = tx0 + 16 * ph + l16;
+                if (xx < W && y < H && co0 < p.Cout) {
+                    const int band = co0 >> 4, a = (co0 >> 2) & 3;
+                    float* o = out + (((long long)n * bands + band) * H4 + 4 * y + a) * W4 + 4 * xx;
+                    *reinterpret_cast<f32x4*>(o) = racc[nt][ph] + b4;
+                }
+            }
     }
 }
 
@@ -225,12 +264,20 @@ extern "C" int kmsr_conv5x5_ps4_fwd_f32(int32_t N, int32_t Cin, int32_t H, int32
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
     p.tiles_x = ceil_div(W, UTW);
     p.tiles = p.tiles_x * ceil_div(H, UTH);
-    p.cgs = ceil_div(Cout, UCOB);
     p.nchunks = ceil_div(Cin, UCK);
-    const long long nblocks = (long long)p.tiles * p.cgs * N;
-    if (nblocks > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv grid too large");
-    p.n_blocks = (int)nblocks;
-    conv5x5_ps4_kernel<<<p.n_blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(x, packed_w, bias, out, p);
+    if ((long long)p.tiles * ceil_div(Cout, UCOB) * N > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv grid too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int full = Cout / UCOB, rem = Cout % UCOB;        // cout groups with 64 real channels; channels of the last, partial group
+    if (full) {
+        p.cg0 = 0; p.cgs = full; p.n_blocks = p.tiles * full * N;
+        conv5x5_ps4_kernel<2, 0><<<p.n_blocks, 256, 0, st>>>(x, packed_w, bias, out, p);
+    }
+    if (rem) {                                              // 16, 32 or 48 (Cout % 16 == 0)
+        p.cg0 = full; p.cgs = 1; p.n_blocks = p.tiles * N;
+        if (rem == 48) conv5x5_ps4_kernel<1, 1><<<p.n_blocks, 256, 0, st>>>(x, packed_w, bias, out, p);
+        else if (rem == 32) conv5x5_ps4_kernel<1, 0><<<p.n_blocks, 256, 0, st>>>(x, packed_w, bias, out, p);
+        else conv5x5_ps4_kernel<0, 1><<<p.n_blocks, 256, 0, st>>>(x, packed_w, bias, out, p);
+    }
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
 }

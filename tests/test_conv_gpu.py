@@ -281,6 +281,8 @@ def test_full_config2_size_consistency(gpu_device):
     (1, 64, 17, 33, 80, True),      # 5 bands: two output-channel groups, ragged tile edges
     (3, 10, 9, 5, 16, False),       # channel count not a multiple of the LDS chunk, image smaller than one tile
     (1, 5, 8, 32, 32, True),
+    (1, 64, 12, 40, 112, True),     # 7 bands: a full 64-channel group + a 48-channel group (32x32 and 16x16 MFMA tiles)
+    (1, 16, 10, 36, 128, False),    # two full groups
 ])
 def test_conv5x5_ps4_vs_torch(N, Cin, H, W, Cout, bias, gpu_device):
     from kmsr_amd.sr import conv5x5_ps4
