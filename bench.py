@@ -237,7 +237,7 @@ class DegradeSRWorkload:
         """MFMA FLOPs one step issues (the degradation and the 64->3 tail are VALU kernels and not counted):
         Winograd layers = algorithmic / 2.25; head = small-Cin MFMA kernel with the 3 bands padded to 2 channel pairs;
         collapsed upsampler = one 5x5 conv 64 -> 48 per LR pixel (32x32x2 tiles for 32 channels + 16x16x4 tiles for 16: no channel
-        padding; + the frame strips, < 2 % of it, not counted)."""
+        padding; + the border-class frame launch, a VALU kernel, not counted)."""
         px = self.B * self.h * self.w
         body = 33 * 18.0 * 64 * 64 / 2.25
         head = 18.0 * 4 * 64
@@ -461,7 +461,7 @@ def main():
     ap.add_argument("--workload", choices=["degrade_sr", "degrade", "train", "sr_bf16"], default="degrade_sr")
     ap.add_argument("--layerwise-upsampler", action="store_true",
                     help="degrade_sr: time the headline with up1 / up2 / tail as three kernels.  Default: the collapsed upsampler (one "
-                         "conv5x5 + PixelShuffle(4) + exact frame strips -- an exact inference-time linear rewrite, pinned against the "
+                         "conv5x5 + PixelShuffle(4) + the 8 border-class operators on the outer LR ring -- an exact inference-time linear rewrite, pinned against the "
                          "layer-by-layer path at full size by tests/test_fullsize_gpu.py); the other form is reported under \"variants\".")
     args = ap.parse_args()
 
@@ -526,7 +526,7 @@ def main():
             "value": round(wl.patches_per_step * args.steps * world / el2, 2), "unit": "LR patches/s",
             "ms_per_step": round(el2 / args.steps * 1e3, 4),
             "what": "up1/PS/up2/PS/tail (linear) as three conv3x3 launches" if fuse else
-                    "up1/PS/up2/PS/tail run as ONE conv5x5 64->48 + PixelShuffle(4) launch + exact 4-px frame strips",
+                    "up1/PS/up2/PS/tail run as ONE conv5x5 64->48 + PixelShuffle(4) launch + one border-class frame launch",
             "issued_mfma_flops_per_step": f2, "issued_mfma_tflops": round(f2 * args.steps * world / el2 / 1e12, 2)}}
 
     if rank == 0:

@@ -291,6 +291,14 @@ int kmsr_conv5x5_ps4_pack_weights_f32(const float* w /* [Cout,Cin,5,5] */, int32
 int kmsr_conv5x5_ps4_fwd_f32(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, const float* x,
                              const float* packed_w, const float* bias, float* out, void* stream);
 
+/* Outer frame of the collapsed upsampler: on the outermost LR row / column the chain's intermediate zero padding turns the
+ * interior 5x5 map into 8 border-class maps (0 top, 1 bottom, 2 left, 3 right -- corners excluded --, 4..7 the corners tl, tr,
+ * bl, br).  wcls [8][Cin][25][16*bands] (tap = dy*5+dx, out channel = band*16 + 4a + b), bcls [8][16*bands]; for every border LR
+ * pixel (i,j) of every image:  y[n, band, 4i+a, 4j+b] = bcls[c] + sum wcls[c][ci][dy][dx] * h[n, ci, i+dy-2, j+dx-2]  (zero
+ * outside the image) is written into y [N,bands,4H,4W] (the interior launch's output).  H, W >= 4, 1..8 bands. */
+int kmsr_upsampler_frame_f32(const float* h, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t bands, const float* wcls,
+                             const float* bcls, float* y, void* stream);
+
 /* ============================================================================================
  * Small-channel convolution with REFLECT padding and per-unit weights -- the KernelGAN generators' forward
  * (DynamicMultiBandLinearGenerator._apply_conv_chain  muti_kernel/networks.py:101-117,

@@ -396,24 +396,27 @@ def conv5x5_ps4(x, packed_w, cout, bias=None, out=None):
 
 
 class _FusedUpsampler:
-    """Inference-time executor of the collapsed x4 upsampler (SRNet.fuse_upsampler):
-    interior = one conv5x5_ps4 launch on the composed weights; the outer HR frame (3 pixels are affected by the zero
-    padding of up2 and tail; 4 are rewritten) is recomputed exactly by running the three layers on four 4-row LR strips (left/right strips transposed,
-    with transposed taps and PixelShuffle sub-pixel order swapped, so every strip is a wide 4-row image)."""
-    R = 4            # LR rows per strip: the layer-by-layer result is exact for HR rows [0, 4R-8]
-    FRAME = 4        # HR frame overwritten (the composed operator is exact from HR row/col 3 inwards)
+    """Inference-time executor of the collapsed x4 upsampler (SRNet.fuse_upsampler).
+
+    Interior: one conv5x5_ps4 launch on the composed weights (compose_upsampler).  The outer HR frame (one LR row / column = 4 HR
+    pixels; the zero padding of up2 and tail reaches 3 of them) is a DIFFERENT but still linear 5x5 map of the LR features, one
+    per border class (top / bottom / left / right / four corners): the intermediate layers' zero padding only truncates paths.
+    Those 8 weight sets are read off the layer-by-layer HIP kernels' responses to unit impulses on a 5x5 LR canvas (every LR
+    pixel of that canvas sits in exactly one class), once per weight version; at run time ONE launch of kmsr_upsampler_frame_f32
+    evaluates them for the 2W + 2(H-2) border LR pixels of every image and writes their 4x4 HR blocks over the interior launch's
+    output.  Images smaller than MIN_SIZE LR pixels on a side run layer by layer (SRNet._forward_infer)."""
+    MIN_SIZE = 8     # every border class must see an untruncated neighbourhood on its far side (>= 5 would do; 8 keeps tiles sane)
 
     def __init__(self):
         self.key = None
 
     @staticmethod
-    def _swap_subpixels(conv):
-        """Weights/bias of the conv that acts on TRANSPOSED images: taps transposed, PixelShuffle channel 4c+2i+j <- 4c+2j+i."""
-        co = torch.arange(conv.out_channels, device=conv.weight.device)
-        src = (co & ~3) | ((co & 1) << 1) | ((co >> 1) & 1)
-        w = conv.weight.detach()[src].transpose(2, 3).contiguous()
-        b = conv.bias.detach()[src].contiguous() if conv.bias is not None else None
-        return w, b
+    def _pack5(w5):
+        lib = L.load()
+        packed = torch.empty(lib.kmsr_conv5x5_ps4_packed_weight_floats(w5.shape[1], w5.shape[0]), device=w5.device, dtype=torch.float32)
+        with torch.cuda.device(w5.device):
+            L.check(lib.kmsr_conv5x5_ps4_pack_weights_f32(L.ptr(w5.contiguous()), w5.shape[1], w5.shape[0], L.ptr(packed), L.current_stream()))
+        return packed
 
     def _prepare(self, net):
         up1, up2 = net.up
@@ -425,31 +428,42 @@ class _FusedUpsampler:
         w5, b5 = compose_upsampler(up1, up2, net.tail)
         w5 = w5.to(dev)
         self.cout5 = w5.shape[0]
-        lib = L.load()
-        self.w5 = torch.empty(lib.kmsr_conv5x5_ps4_packed_weight_floats(w5.shape[1], w5.shape[0]), device=dev,
-                              dtype=torch.float32)
-        with torch.cuda.device(dev):
-            L.check(lib.kmsr_conv5x5_ps4_pack_weights_f32(L.ptr(w5), w5.shape[1], w5.shape[0], L.ptr(self.w5),
-                                                          L.current_stream()))
+        self.w5 = self._pack5(w5)
         self.b5 = b5.to(dev)
-        # layer-by-layer weights for the frame strips: as stored (top/bottom) and for transposed strips (left/right)
-        self.layers = {}
-        for tag in ("n", "t"):
-            ls = []
-            for cv in (up1, up2, net.tail):
-                if tag == "n":
-                    w, b = cv.weight.detach().contiguous(), (cv.bias.detach().contiguous() if cv.bias is not None else None)
-                elif cv is net.tail:
-                    w, b = cv.weight.detach().transpose(2, 3).contiguous(), (cv.bias.detach().contiguous() if cv.bias is not None else None)
-                else:
-                    w, b = self._swap_subpixels(cv)
-                ls.append((w, b, {}))           # packed weights per algorithm, filled on first use
-            self.layers[tag] = ls
+        # layer-by-layer weights for the impulse probing of the border classes
+        self.layers = [(cv.weight.detach().contiguous(), cv.bias.detach().contiguous() if cv.bias is not None else None, {})
+                       for cv in (up1, up2, net.tail)]              # (w, b, packed weights per algorithm)
+        self._border_sets(net, dev)
         self.key = key
 
-    def _chain(self, tag, s, use_wino):
-        """up1 -> PS -> up2 -> PS -> tail on a strip batch [M,F,R,L] with the HIP 3x3 kernels."""
-        for i, (w, b, packs) in enumerate(self.layers[tag]):
+    def _border_sets(self, net, dev):
+        """5x5 weights + bias of the 8 border classes from ONE run of the three layers on the 25 F unit impulses of a 5x5 canvas."""
+        F, bands = net.up[0].in_channels, net.tail.out_channels
+        S = 5
+        imp = torch.zeros(S * S * F + 1, F, S, S, device=dev)          # image (p*S + q)*F + ci has a 1 at (ci, p, q); the last one is all zero
+        idx = torch.arange(S * S * F, device=dev)
+        imp[idx, idx % F, (idx // F) // S, (idx // F) % S] = 1.0
+        r = self._chain(imp, net.use_winograd)                          # [25F+1, bands, 20, 20]
+        zero = r[-1]
+        r = (r[:-1] - zero).view(S, S, F, bands, 4 * S, 4 * S)          # [p, q, ci, band, Y, X]
+        order = {(-1, 0): 0, (1, 0): 1, (0, -1): 2, (0, 1): 3, (-1, -1): 4, (-1, 1): 5, (1, -1): 6, (1, 1): 7}    # kmsr.h class ids
+        self.wcls = torch.zeros(8, F, 25, bands * 16, device=dev)
+        self.bcls = torch.zeros(8, bands * 16, device=dev)
+        for (ri, ci_), c in order.items():
+            i0, j0 = 2 + 2 * ri, 2 + 2 * ci_                            # the canvas pixel of this class
+            w = torch.zeros(bands, 4, 4, F, 5, 5, device=dev)           # [band, a, b, ci, dy, dx]
+            for dy in range(5):
+                for dx in range(5):
+                    p, q = i0 + dy - 2, j0 + dx - 2
+                    if 0 <= p < S and 0 <= q < S:
+                        w[:, :, :, :, dy, dx] = r[p, q, :, :, 4 * i0:4 * i0 + 4, 4 * j0:4 * j0 + 4].permute(1, 2, 3, 0)
+            self.wcls[c] = w.permute(3, 4, 5, 0, 1, 2).reshape(F, 25, bands * 16)
+            self.bcls[c] = zero[:, 4 * i0:4 * i0 + 4, 4 * j0:4 * j0 + 4].reshape(bands * 16)
+        self.bands = bands
+
+    def _chain(self, s, use_wino):
+        """up1 -> PS -> up2 -> PS -> tail on a batch [M,F,R,L] with the HIP 3x3 kernels."""
+        for i, (w, b, packs) in enumerate(self.layers):
             algo = pick_algo(w.shape[1], w.shape[0], 1, s.shape[-1], use_wino)
             if algo not in packs:
                 packs[algo] = pack_for(algo, w)
@@ -459,14 +473,12 @@ class _FusedUpsampler:
     def __call__(self, net, h):
         self._prepare(net)
         N, F, H, W = h.shape
-        R, E = self.R, self.FRAME
+        assert min(H, W) >= self.MIN_SIZE
         y = conv5x5_ps4(h, self.w5, self.cout5, bias=self.b5)
-        tb = self._chain("n", torch.cat([h[:, :, :R, :], h[:, :, H - R:, :]], 0), net.use_winograd)          # [2N,C,4R,4W]
-        y[:, :, :E, :] = tb[:N, :, :E, :]
-        y[:, :, 4 * H - E:, :] = tb[N:, :, 4 * R - E:, :]
-        lr = self._chain("t", torch.cat([h[:, :, :, :R], h[:, :, :, W - R:]], 0).transpose(2, 3), net.use_winograd)  # [2N,C,4R,4H]
-        y[:, :, :, :E] = lr[:N, :, :E, :].transpose(2, 3)
-        y[:, :, :, 4 * W - E:] = lr[N:, :, 4 * R - E:, :].transpose(2, 3)
+        lib = L.load()
+        with torch.cuda.device(h.device):
+            L.check(lib.kmsr_upsampler_frame_f32(L.ptr(h), N, F, H, W, self.bands, L.ptr(self.wcls), L.ptr(self.bcls), L.ptr(y),
+                                                 L.current_stream()))
         return y
 
 
@@ -492,7 +504,7 @@ class SRNet(nn.Module):
         self.tail = nn.Conv2d(n_feats, n_colors, 3, padding=1)
         self._caches = {}
         self.use_winograd = True    # inference path: Winograd F(2x2,3x3) MFMA kernel for the F->F / F->4F convs
-        self.fuse_upsampler = True   # inference path, x4 only: up1/PS/up2/PS/tail (linear) run as one 5x5 conv + PS4 + exact frame strips
+        self.fuse_upsampler = True   # inference path, x4 only: up1/PS/up2/PS/tail (linear) run as one 5x5 conv + PS4 + the border-class frame launch
         #                              (same outputs, tests/test_fullsize_gpu.py; False = three conv3x3 launches)
         self._fused_up = _FusedUpsampler()
 
@@ -538,7 +550,7 @@ class SRNet(nn.Module):
             t = self._conv(f"b{i}.1", blk.conv1, h, relu=True)
             h = self._conv(f"b{i}.2", blk.conv2, t, residual=h)
         h = self._conv("body_tail", self.body_tail, h, residual=f)
-        if self.fuse_upsampler and len(self.up) == 2 and min(h.shape[-2:]) >= 2 * _FusedUpsampler.R:
+        if self.fuse_upsampler and len(self.up) == 2 and min(h.shape[-2:]) >= _FusedUpsampler.MIN_SIZE:
             return self._fused_up(self, h)
         for i, up in enumerate(self.up):
             h = self._conv(f"up{i}", up, h, pixel_shuffle=True)      # conv F->4F with PixelShuffle(2) fused into the store
