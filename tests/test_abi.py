@@ -166,3 +166,18 @@ def test_pick_algo_dispatch():
     assert pick_algo(64, 3, 1, 1024) == "direct"                # tail: small-Cout VALU kernel
     assert pick_algo(64, 64, 2, 256) == "direct"                # stride 2 (selector)
     assert pick_algo(64, 64, 1, 256, use_winograd=False) == "direct"
+
+
+def test_pick_algo_routes_layers_to_their_kernels():
+    """Host-side dispatch of the 3x3 layers (no GPU needed): which C-ABI entry point serves which layer shape."""
+    from kmsr_amd.sr import pick_algo
+    assert pick_algo(64, 64, 1, 256) == "winograd_vreg"              # SR body: persistent V-in-registers Winograd kernel (W % 4 == 0)
+    assert pick_algo(64, 256, 1, 254) == "winograd"                  # even width that is not a multiple of 4: register-staged Winograd
+    assert pick_algo(64, 64, 1, 255) == "direct"                     # odd width
+    assert pick_algo(64, 64, 2, 256) == "direct"                     # stride 2 (SelectorNet / ConditionEncoder)
+    assert pick_algo(64, 5, 1, 1024) == "direct"                     # SR tail: Cout <= 8 -> the small-Cout VALU kernel behind kmsr_conv3x3_fwd_f32
+    assert pick_algo(3, 64, 1, 256) == "direct"                      # head with an epilogue the small-Cin kernel does not have
+    assert pick_algo(3, 64, 1, 256, plain=True) == "smallci"         # head / tail data gradient: bias + ReLU epilogue only
+    assert pick_algo(5, 64, 1, 250, plain=True) == "direct"          # small-Cin kernel needs W % 4 == 0
+    assert pick_algo(64, 64, 1, 256, use_winograd=False) == "direct"
+    assert pick_algo(64, 2048, 1, 256) == "winograd"                 # bias vector would not fit the persistent kernel's LDS staging
