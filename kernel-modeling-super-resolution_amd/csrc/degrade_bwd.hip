@@ -38,6 +38,7 @@ struct BwdParams {
 };
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 // TF/TK > 0: factor and (square) kernel size are compile-time constants (V-B: 4, 13), so the index arithmetic of the
 // tile fill and of the tap loop needs no runtime divisions; TF = TK = 0: generic.
@@ -285,6 +286,187 @@ __global__ void __launch_bounds__(BTHREADS) degrade_bwd_vb_kernel(BwdParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Strip-streaming form of the V-B kernel (W % 16 == 0, zero padding): the default for the trainer's shapes.
+// The per-tile chain  load -> barrier -> taps -> barrier -> reduce  of the kernel above leaves a workgroup without bytes in flight
+// for most of its life (0.35 of the HBM peak; timing-only ablations, tools/diag/make_ablate_dbwd.py: loads alone 0.165 ms, taps
+// alone 0.137 ms, together 0.255 ms).  Here a workgroup owns a COLUMN STRIP (16 LR columns = 80 aligned HR columns) of a plane
+// and walks it top to bottom in blocks of 64 HR rows (16 LR rows):
+//   * a three-slot ring of blocks in LDS, filled by LDS-DMA (no staging registers): while block k is consumed, block k+1 has
+//     (mostly) landed and block k+2 is in flight -- every HR row of the strip is fetched exactly once, the 9 halo rows a step needs
+//     below its own block are the head of the next ring slot;
+//   * counted waits: a wave issues the same 3 DMA instructions per block (lanes outside the image read a zero page, so the count
+//     never depends on the data), hence `vmcnt(3)` = "everything but my share of the newest block has landed";
+//   * the 169 tap sums (and the sigma sum) stay in registers for the whole strip: one reduction / store per strip instead of
+//     one per tile, and 16x fewer partials for the second kernel.
+// LDS-DMA writes 64 lanes x 16 bytes contiguously, so a ring row is 21 float4 (20 data + 1 filler, never read): pitch 84 floats
+// as above, a block = 64 rows = exactly 21 instructions (waves 0..6 x 3); wave 7 fetches the block's 256 gradients (one
+// instruction) and owns the sigma sum.  Workgroups of one XCD take neighbouring strips, so the 16 shared columns hit its L2.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+constexpr int VS_BR = BT * VB_F;                     // 64 HR rows per block
+constexpr int VS_Q = VB_APITCH / 4;                  // 21 float4 per ring row
+constexpr int VS_BF = VS_BR * VB_APITCH;             // 5376 floats per ring slot
+constexpr int VS_NI = 3;                             // DMA instructions per wave (0..6) and block
+constexpr int VS_SLOTS = 3;
+constexpr int VS_UP = 7;                             // tap-row pairs (u, u + 7); u + 7 = 13 is computed and dropped
+static_assert(7 * VS_NI * 64 * 4 == VS_BF, "a block is 21 whole DMA instructions");
+__device__ __attribute__((aligned(16))) float g_zero_page[4];      // zero-initialised; what lanes outside the image fetch
+
+struct StripCursor {          // block `kb` of this workgroup's job `m`
+    int m, kb, plane, strip;
+    bool live;
+};
+
+__global__ void __launch_bounds__(BTHREADS) degrade_bwd_vb_strip_kernel(BwdParams p, int jobs) {
+    // ONE LDS object: with a second __shared__ array beside the LDS-DMA target hipcc (ROCm 7.2) waits vmcnt(0) before the first
+    // ds_read of every step, i.e. for the block that was just issued (checked in the .s)
+    __shared__ __attribute__((aligned(16))) float lds[VS_SLOTS * VS_BF + VS_SLOTS * BT * BT + BT * VB_TAPS + 64];
+    float (*xs)[VS_BF] = reinterpret_cast<float (*)[VS_BF]>(lds);
+    float (*gs)[BT * BT] = reinterpret_cast<float (*)[BT * BT]>(lds + VS_SLOTS * VS_BF);
+    float* red = lds + VS_SLOTS * VS_BF + VS_SLOTS * BT * BT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x;
+    // workgroups are dealt to the 8 XCDs round-robin: give the workgroups of one XCD consecutive jobs
+    const int v = G % 8 == 0 ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    if (v >= jobs) return;                           // block-uniform
+    const int strips = p.tiles_x, nsteps = p.tiles / p.tiles_x, NB = nsteps + 1;
+    const int njobs = (jobs - v + G - 1) / G;        // jobs v, v + G, v + 2 G, ...
+    const int TB = njobs * NB;
+
+    // this thread's three float4 of every block (waves 0..6), or its float4 of the gradients (wave 7)
+    int roff[VS_NI], rr[VS_NI], cq[VS_NI];
+#pragma unroll
+    for (int k = 0; k < VS_NI; ++k) {
+        const int e = ((wv % 7) * VS_NI + k) * 64 + lane;
+        rr[k] = e / VS_Q;
+        cq[k] = 4 * (e - rr[k] * VS_Q);
+        roff[k] = rr[k] * (int)p.sH + cq[k];
+    }
+    const int gi = lane >> 2, gj = 4 * (lane & 3);
+    const float* zp = g_zero_page;
+
+    auto cursor = [&](int m, int kb) {
+        StripCursor c{m, kb, 0, 0, m < njobs};
+        const int job = v + G * (c.live ? m : 0);
+        c.plane = job / strips;
+        c.strip = job - c.plane * strips;
+        return c;
+    };
+    auto advance = [&](StripCursor c) { return c.kb + 1 < NB ? StripCursor{c.m, c.kb + 1, c.plane, c.strip, c.live} : cursor(c.m + 1, 0); };
+    auto issue = [&](const StripCursor& c, int slot) {          // always the same number of vector-memory instructions per wave
+        if (wv < 7) {
+            const int n = c.plane / p.C, ch = c.plane - n * p.C;
+            const float* __restrict__ x = p.hr + n * p.sN + ch * p.sC;
+            const int y0 = c.kb * VS_BR - VB_K / 2, xa = c.strip * (BT * VB_F) - VB_K / 2 - VB_AOFF;
+            const float* __restrict__ xo = x + (long long)y0 * p.sH + xa;
+#pragma unroll
+            for (int k = 0; k < VS_NI; ++k) {
+                const int gy = y0 + rr[k], gx = xa + cq[k];
+                const bool ok = c.live && cq[k] < 4 * VB_AQ && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+                float* dst = xs[slot] + (wv * VS_NI + k) * 256;         // wave-uniform; the lane's slot is dst + 4 * lane
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(ok ? xo + roff[k] : zp), (lds_void_t*)dst, 16, 0, 0);
+            }
+        } else {
+            const int i = c.kb * BT + gi, j = c.strip * BT + gj;
+            const bool ok = c.live && i < p.h && j < p.w;               // w % 4 == 0: a float4 is wholly inside or outside
+            const float* __restrict__ gp = p.g + (long long)c.plane * p.h * p.w + (long long)i * p.w + j;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(ok ? gp : zp), (lds_void_t*)gs[slot], 16, 0, 0);
+        }
+    };
+
+    // tap loop: thread (LR row i of the step, tap rows u and u + 7, v mod 4) -- 16 x 7 x 4 = 448 threads = waves 0..6.  The two
+    // tap rows share the gradient, so one v_pk_fma_f32 (gradient broadcast to both halves) does two of the 128 FMAs per thread and
+    // step; taps v, v + 4, v + 8, v + 12 read the same samples at neighbouring LR columns (19 samples feed 16 x 4 products).
+    const int vm = tid & 3, up = (tid >> 2) % VS_UP, li = tid / (4 * VS_UP);
+    const int row0 = li * VB_F + up, row1 = row0 + VS_UP;                // ring rows of the two tap rows (row1 <= 73: inside slot t + 1)
+    f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    float sg = 0.f;
+
+    StripCursor cur = cursor(0, 0), nxt = advance(cur), nn = advance(nxt);
+    issue(cur, 0);
+    issue(nxt, 1);
+    int sl = 0;                                                          // ring slot of the current block
+    for (int t = 0; t < TB; ++t) {
+        // landed before this step may run: blocks <= t, and the first 10 rows of block t + 1 (inside wave 0's share of it)
+        asm volatile("" ::: "memory");
+        if (wv == 0) __builtin_amdgcn_s_waitcnt(0x0070 | 0);            // vmcnt(0), lgkmcnt(0)
+        else if (wv < 7) __builtin_amdgcn_s_waitcnt(0x0070 | VS_NI);    // vmcnt(3): all but my share of block t + 1
+        else __builtin_amdgcn_s_waitcnt(0x0070 | 1);                    // vmcnt(1): all but the gradients of block t + 1
+        __builtin_amdgcn_s_barrier();                // NOT __syncthreads(): its fence would drain vmcnt to 0, i.e. wait for block t + 1
+        asm volatile("" ::: "memory");
+        const int sl1 = sl == VS_SLOTS - 1 ? 0 : sl + 1, sl2 = sl1 == VS_SLOTS - 1 ? 0 : sl1 + 1;
+        issue(nn, sl2);                              // slot of block t - 1: its last readers finished before this barrier
+        if (cur.kb < nsteps) {
+            const float* gb = gs[sl];
+            if (wv < 7) {
+                const float* xr0 = (row0 < VS_BR ? xs[sl] + row0 * VB_APITCH : xs[sl1] + (row0 - VS_BR) * VB_APITCH) + VB_AOFF + vm;
+                const float* xr1 = (row1 < VS_BR ? xs[sl] + row1 * VB_APITCH : xs[sl1] + (row1 - VS_BR) * VB_APITCH) + VB_AOFF + vm;
+                f32x2 xv[BT + 3];
+#pragma unroll
+                for (int j = 0; j < BT + 3; ++j) xv[j] = f32x2{xr0[VB_F * j], xr1[VB_F * j]};
+                const f32x4* g4 = reinterpret_cast<const f32x4*>(gb + li * BT);
+#pragma unroll
+                for (int q = 0; q < BT / 4; ++q) {
+                    const f32x4 gq = g4[q];
+                    const float gk[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_elementwise_fma(f32x2{gk[k], gk[k]}, xv[4 * q + k + tt], acc[tt]);
+                }
+            } else if (p.want_sigma) {               // the last wave is idle in the tap loop: it owns the sigma sum
+                const int ib = lane / BT, jj = lane % BT;
+                const int i = cur.kb * BT + 4 * ib, j = cur.strip * BT + jj;
+                float z[4];
+                eps4(p.seed, p.offset, (unsigned)cur.plane, (unsigned)(i >> 2), (unsigned)j, z);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sg = fmaf(gb[(4 * ib + k) * BT + jj], z[k], sg);   // gradients are 0 outside the image
+            }
+        } else {                                     // the strip's last (halo-only) block: hand the sums over
+            if (wv < 7) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int vv = vm + 4 * tt;
+                    if (vv < VB_K) {
+                        red[li * VB_TAPS + up * VB_K + vv] = acc[tt].x;
+                        if (up + VS_UP < VB_K) red[li * VB_TAPS + (up + VS_UP) * VB_K + vv] = acc[tt].y;
+                    }
+                    acc[tt] = f32x2{0.f, 0.f};
+                }
+            } else {
+                red[BT * VB_TAPS + lane] = sg;
+                sg = 0.f;
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only: the blocks in flight stay in flight
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            float* out = p.part + ((long long)cur.plane * strips + cur.strip) * (VB_TAPS + 1);
+            if (tid < VB_TAPS) {
+                float a = red[tid];
+#pragma unroll
+                for (int k = 1; k < BT; ++k) a += red[k * VB_TAPS + tid];
+                out[tid] = a;
+            }
+            if (tid == 256) {
+                float a = 0.f;
+                if (p.want_sigma)
+                    for (int k = 0; k < 64; ++k) a += red[BT * VB_TAPS + k];
+                out[VB_TAPS] = a;
+            }
+        }
+        cur = nxt;
+        nxt = nn;
+        nn = advance(nn);
+        sl = sl1;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0070 | 0);          // the two look-ahead fetches past the end (zero page) must not outlive the LDS
+}
+
 // dk[plane][tap] = sum_tiles part[plane][tile][tap]; dsigma[plane] likewise.  Fixed summation order (8 interleaved
 // running sums per output, combined pairwise) so results are bit-reproducible; the 8 loads of a round are independent,
 // which keeps the tile loop from serialising on memory latency.
@@ -308,6 +490,15 @@ __global__ void degrade_bwd_reduce_kernel(const float* __restrict__ part, int ti
             dsigma[plane] = r;
         }
     }
+}
+
+int cu_count() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    return cus;
 }
 
 int check_desc(const kmsr_degrade_desc* d) {
@@ -369,10 +560,18 @@ extern "C" int kmsr_degrade_bwd_f32(const kmsr_degrade_desc* d, const float* hr,
     const long long nblocks = planes * p.tiles;
     if (nblocks > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "grid too large");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int reduce_tiles = p.tiles;
     if (p.F == VB_F && p.kh == VB_K && p.kw == VB_K) {
         const bool aligned = p.pad_zero && d->W % 4 == 0 && p.sH % 4 == 0 && p.sC % 4 == 0 && p.sN % 4 == 0 &&
                              reinterpret_cast<uintptr_t>(hr) % 16 == 0;
-        if (aligned) degrade_bwd_vb_kernel<true><<<(int)nblocks, BTHREADS, 0, stream>>>(p);
+        const bool strip = aligned && d->W % 16 == 0 && reinterpret_cast<uintptr_t>(grad_lr) % 16 == 0 &&
+                           (long long)d->H * p.sH < (1ll << 31);
+        if (strip) {
+            const int jobs = (int)(planes * p.tiles_x);
+            const int wgs = std::min(jobs, 2 * cu_count());              // 78 KB of LDS each: two per CU
+            degrade_bwd_vb_strip_kernel<<<wgs, BTHREADS, 0, stream>>>(p, jobs);
+            reduce_tiles = p.tiles_x;                                    // one partial per column strip
+        } else if (aligned) degrade_bwd_vb_kernel<true><<<(int)nblocks, BTHREADS, 0, stream>>>(p);
         else degrade_bwd_vb_kernel<false><<<(int)nblocks, BTHREADS, 0, stream>>>(p);
     } else {
         if (lds > 64 * 1024)
@@ -381,7 +580,7 @@ extern "C" int kmsr_degrade_bwd_f32(const kmsr_degrade_desc* d, const float* hr,
         degrade_bwd_kernel<0, 0><<<(int)nblocks, BTHREADS, lds, stream>>>(p);
     }
     KMSR_HIP_CHECK(hipGetLastError());
-    degrade_bwd_reduce_kernel<<<(int)planes, 256, 0, stream>>>(p.part, p.tiles, ntaps, dkernels, dsigma);
+    degrade_bwd_reduce_kernel<<<(int)planes, 256, 0, stream>>>(p.part, reduce_tiles, ntaps, dkernels, dsigma);
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
 }

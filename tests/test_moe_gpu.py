@@ -120,7 +120,11 @@ MB = golden("moe_backward.npz")
 
 @pytest.mark.parametrize("shape,k,f,pad", [((3, 5, 40, 44), 13, 4, "zero"), ((2, 3, 67, 129), 13, 4, "replicate"),
                                            ((2, 2, 33, 70), 7, 2, "zero"), ((1, 5, 32, 32), 1, 1, "zero"),
-                                           ((1, 1, 300, 260), 13, 4, "zero")])
+                                           ((1, 1, 300, 260), 13, 4, "zero"),
+                                           # W % 16 == 0: the strip-streaming kernel (ragged last step / last strip, one-step strips,
+                                           # more (plane, strip) jobs than resident workgroups)
+                                           ((2, 3, 72, 96), 13, 4, "zero"), ((1, 2, 200, 64), 13, 4, "zero"),
+                                           ((130, 5, 16, 16), 13, 4, "zero"), ((1, 1, 272, 160), 13, 4, "zero")])
 def test_degrade_backward_vs_oracle(shape, k, f, pad, gpu_device):
     """kmsr_degrade_bwd_f32 == the float64 restatement (which test_oracle_golden pins to the reference's autograd)."""
     from kmsr_amd.degradation import degrade_backward
