@@ -11,9 +11,9 @@
 // of one plane: the HR halo tile ((16-1)F+kh rows) and the 256 upstream gradients go to LDS, threads accumulate taps
 // over the tile (generic kernel: one tap per thread; V-B kernel below: 4 taps per thread, register blocked); per-tile
 // partial sums go to the workspace and a second kernel adds them in a fixed order (bit-reproducible, no float atomics).
-// Measured at the config-3 batch (HR [32,5,1024,1024]): 0.46 ms = 1.5 TB/s algorithmic (0.19 of HBM peak), 0.55 ms with
-// dsigma -- bounded by the tile fill's index arithmetic and the per-tile barriers, not by HBM; a strip-persistent
-// variant with register prefetch was slower (0.59 ms: 128+ VGPRs, 2 workgroups per CU).
+// Three kernels: the strip-streaming V-B kernel (factor 4, 13x13, W % 16 == 0, zero padding -- the trainer's shapes; 0.184 ms at the
+// config-3 batch HR [32,5,1024,1024] = 0.48 of the HBM peak, profiles/r02_degrade_bwd_strip.log), the per-tile V-B kernel for the
+// other alignments / replicate padding (0.257 ms), and the generic per-tile kernel for every other factor / kernel size.
 #include "kmsr_common.h"
 #include "kmsr_noise.h"
 
