@@ -50,9 +50,10 @@ __global__ void __launch_bounds__(256) conv_reflect_kernel(const float* __restri
     }
     __syncthreads();
     const int py = tid / RT, px = tid % RT;
-    float acc[COUT];
+    kmsr_f32x2 acc2[(COUT + 1) / 2];
+    float accr = (COUT & 1) && bias ? bias[COUT - 1] : 0.f;
 #pragma unroll
-    for (int o = 0; o < COUT; ++o) acc[o] = bias ? bias[o] : 0.f;
+    for (int q = 0; q < COUT / 2; ++q) acc2[q] = bias ? kmsr_f32x2{bias[2 * q], bias[2 * q + 1]} : kmsr_f32x2{0.f, 0.f};
     const float* __restrict__ wu = w + (long long)u * wstride;                 // wave-uniform
     for (int c = 0; c < Cin; ++c) {
         const float* tc = tile + c * IT * IT + py * IT + px;
@@ -62,15 +63,14 @@ __global__ void __launch_bounds__(256) conv_reflect_kernel(const float* __restri
             for (int b = 0; b < KS; ++b) {
                 const float v = tc[a * IT + b];
                 const float* __restrict__ wt = wu + ((long long)c * KS * KS + a * KS + b) * COUT;
-#pragma unroll
-                for (int o = 0; o < COUT; ++o) acc[o] = fmaf(wt[o], v, acc[o]);
+fma_row<COUT>(wt, v, acc2, accr);
             }
     }
     const int y = ty0 + py, xx = tx0 + px;
     if (y < H && xx < W) {
         float* ou = out + (long long)u * COUT * H * W + (long long)y * W + xx;
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) ou[(long long)o * H * W] = acc[o];
+        for (int o = 0; o < COUT; ++o) ou[(long long)o * H * W] = fma_row_get<COUT>(acc2, accr, o);
     }
 }
 

@@ -56,9 +56,10 @@ __global__ void __launch_bounds__(256) convk_dgrad_kernel(const float* __restric
     __syncthreads();
     const int py = tid / RT, px = tid % RT;
     const int y = ty0 + py, xx = tx0 + px;
-    float acc[CDX];
+    kmsr_f32x2 acc2[(CDX + 1) / 2];
+    float accr = 0.f;
 #pragma unroll
-    for (int o = 0; o < CDX; ++o) acc[o] = 0.f;
+    for (int q = 0; q < (CDX + 1) / 2; ++q) acc2[q] = kmsr_f32x2{0.f, 0.f};
     const float* __restrict__ wu = wT + (long long)u * wstride;
     // rows / cols of the LDS tile that tap (a,b) reads for source v:  (v - t0) + 2P - a
     bool border = false;
@@ -72,8 +73,7 @@ __global__ void __launch_bounds__(256) convk_dgrad_kernel(const float* __restric
                 for (int b = 0; b < KS; ++b) {
                     const float v = tc[-a * IT - b];
                     const float* __restrict__ wt = wu + ((long long)c * KS * KS + a * KS + b) * CDX;
-#pragma unroll
-                    for (int o = 0; o < CDX; ++o) acc[o] = fmaf(wt[o], v, acc[o]);
+fma_row<CDX>(wt, v, acc2, accr);
                 }
         }
     } else {
@@ -97,15 +97,14 @@ __global__ void __launch_bounds__(256) convk_dgrad_kernel(const float* __restric
                             if (r >= 0 && r < IT && cc >= 0 && cc < IT) v += tc[r * IT + cc];
                         }
                     const float* __restrict__ wt = wu + ((long long)c * KS * KS + a * KS + b) * CDX;
-#pragma unroll
-                    for (int o = 0; o < CDX; ++o) acc[o] = fmaf(wt[o], v, acc[o]);
+fma_row<CDX>(wt, v, acc2, accr);
                 }
         }
     }
     if (y < H && xx < W) {
         float* ou = dx + (long long)u * CDX * H * W + (long long)y * W + xx;
 #pragma unroll
-        for (int o = 0; o < CDX; ++o) ou[(long long)o * H * W] = acc[o];
+        for (int o = 0; o < CDX; ++o) ou[(long long)o * H * W] = fma_row_get<CDX>(acc2, accr, o);
     }
 }
 
