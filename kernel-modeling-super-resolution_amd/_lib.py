@@ -109,6 +109,8 @@ SYMBOLS = {
     "kmsr_conv_reflect_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "kmsr_convk_fwd_f32": (C.c_int, [C.POINTER(ConvKDesc), _vp, _vp, _vp, _vp, _vp]),
     "kmsr_convk_dgrad_f32": (C.c_int, [C.POINTER(ConvKDesc), _vp, _vp, _vp, _vp]),
+    "kmsr_convk_dgrad_workspace_bytes": (C.c_size_t, [C.POINTER(ConvKDesc)]),
+    "kmsr_convk_dgrad_ws_f32": (C.c_int, [C.POINTER(ConvKDesc), _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "kmsr_convk_wgrad_workspace_bytes": (_sz, [C.POINTER(ConvKDesc)]),
     "kmsr_convk_wgrad_f32": (C.c_int, [C.POINTER(ConvKDesc), _vp, _vp, _vp, _vp, _sz, _vp]),
     "kmsr_compose_kernels_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),

@@ -5,87 +5,121 @@
 // ([ci][tap][co] contiguous per unit) so they arrive through the scalar cache and feed v_fmac as SGPR operands.
 #include "kmsr_common.h"
 
+#include <algorithm>
+
 namespace kmsr {
 namespace {
 
 constexpr int RT = 16;   // output tile edge
+constexpr int CK = 64;   // input channels per LDS chunk, one pixel per thread (= all of them: see the note in the kernel)
+constexpr int CK2 = 8;   // ... two pixels per thread
 
 __device__ __forceinline__ int reflect_idx(int v, int n) {
     v = v < 0 ? -v : v;
     return v >= n ? 2 * (n - 1) - v : v;
 }
 
-template <int KS, int COUT, bool ZERO>
+// NPX = output pixels per thread (columns px, px + 16, ...): every scalar-loaded weight pair feeds NPX packed FMAs, which divides
+// the scalar-cache traffic per FMA -- the measured bound of this kernel -- by NPX; the tile is then RT rows x 16 NPX columns and the
+// input channels go through LDS in chunks of CKN so that the wider tile still fits several workgroups per CU.
+template <int KS, int COUT, bool ZERO, int NPX>
 __global__ void __launch_bounds__(256) conv_reflect_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ out, int Cin,
                                                            int H, int W, int tiles_x, int tiles, long long wstride) {
-    constexpr int P = KS / 2, IT = RT + KS - 1;
-    extern __shared__ __attribute__((aligned(16))) float tile[];   // [Cin][IT][IT]
+    constexpr int P = KS / 2, IT = RT + KS - 1, ITW = RT * NPX + KS - 1, CKN = NPX > 1 ? CK2 : CK;
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [min(Cin, CKN)][IT][ITW]: one chunk of input channels
     const int tid = threadIdx.x;
     const int u = blockIdx.x / tiles, t = blockIdx.x % tiles;
-    const int ty0 = (t / tiles_x) * RT, tx0 = (t % tiles_x) * RT;
+    const int ty0 = (t / tiles_x) * RT, tx0 = (t % tiles_x) * (RT * NPX);
     const float* __restrict__ xu = x + (long long)u * Cin * H * W;
-    // 8 loads in flight per thread before any is written to LDS (a rolled load->store loop pays a round trip per element)
-    const int n_el = Cin * IT * IT;
-    for (int e0 = 0; e0 < n_el; e0 += 256 * 8) {
-        float v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = min(e0 + tid + 256 * q, n_el - 1);
-            const int c = e / (IT * IT), rem = e - c * (IT * IT), r = rem / IT, cc = rem - r * IT;
-            if constexpr (ZERO) {
-                const int gy = ty0 + r - P, gx = tx0 + cc - P;
-                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                v[q] = in ? xu[((long long)c * H + gy) * W + gx] : 0.f;
-            } else {
-                const int gy = reflect_idx(min(ty0 + r - P, H - 1 + P), H), gx = reflect_idx(min(tx0 + cc - P, W - 1 + P), W);
-                v[q] = xu[((long long)c * H + gy) * W + gx];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = e0 + tid + 256 * q;
-            if (e < n_el) tile[e] = v[q];
-        }
-    }
-    __syncthreads();
     const int py = tid / RT, px = tid % RT;
-    kmsr_f32x2 acc2[(COUT + 1) / 2];
-    float accr = (COUT & 1) && bias ? bias[COUT - 1] : 0.f;
+    kmsr_f32x2 acc2[NPX][(COUT + 1) / 2];
+    float accr[NPX];
 #pragma unroll
-    for (int q = 0; q < COUT / 2; ++q) acc2[q] = bias ? kmsr_f32x2{bias[2 * q], bias[2 * q + 1]} : kmsr_f32x2{0.f, 0.f};
+    for (int j = 0; j < NPX; ++j) {
+        accr[j] = (COUT & 1) && bias ? bias[COUT - 1] : 0.f;
+#pragma unroll
+        for (int q = 0; q < COUT / 2; ++q) acc2[j][q] = bias ? kmsr_f32x2{bias[2 * q], bias[2 * q + 1]} : kmsr_f32x2{0.f, 0.f};
+    }
     const float* __restrict__ wu = w + (long long)u * wstride;                 // wave-uniform
-    for (int c = 0; c < Cin; ++c) {
-        const float* tc = tile + c * IT * IT + py * IT + px;
+    // Measured (5x5, 32 -> 32, 40 units at 256^2, profiles/r02_n1_kernelgan_trainer_timing.log), one pixel per thread: all channels
+    // in LDS (51 KB, 3 workgroups per CU) 2.69 ms; chunks of 8 (13 KB, 7 workgroups per CU) 3.08 ms; tap t + 1's scalar loads and LDS
+    // read requested before tap t's FMAs (checked in the .s) 3.51 ms; scalar vs packed FMAs: no difference.  The waves sit at 10 %
+    // issue: a unit's weights (102 KB) stream through the 16 KB scalar cache once per wave, and its miss throughput -- not FMA issue,
+    // not load latency -- is the bound.
+    for (int c0 = 0; c0 < Cin; c0 += CKN) {
+        const int nc = min(CKN, Cin - c0);
+        if (c0) __syncthreads();
+        // 8 loads in flight per thread before any is written to LDS (a rolled load->store loop pays a round trip per element)
+        const int n_el = nc * IT * ITW;
+        for (int e0 = 0; e0 < n_el; e0 += 256 * 8) {
+            float v[8];
 #pragma unroll
-        for (int a = 0; a < KS; ++a)
-#pragma unroll
-            for (int b = 0; b < KS; ++b) {
-                const float v = tc[a * IT + b];
-                const float* __restrict__ wt = wu + ((long long)c * KS * KS + a * KS + b) * COUT;
-fma_row<COUT>(wt, v, acc2, accr);
+            for (int q = 0; q < 8; ++q) {
+                const int e = min(e0 + tid + 256 * q, n_el - 1);
+                const int c = e / (IT * ITW), rem = e - c * (IT * ITW), r = rem / ITW, cc = rem - r * ITW;
+                if constexpr (ZERO) {
+                    const int gy = ty0 + r - P, gx = tx0 + cc - P;
+                    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                    v[q] = in ? xu[((long long)(c0 + c) * H + gy) * W + gx] : 0.f;
+                } else {
+                    const int gy = reflect_idx(min(ty0 + r - P, H - 1 + P), H), gx = reflect_idx(min(tx0 + cc - P, W - 1 + P), W);
+                    v[q] = xu[((long long)(c0 + c) * H + gy) * W + gx];
+                }
             }
-    }
-    const int y = ty0 + py, xx = tx0 + px;
-    if (y < H && xx < W) {
-        float* ou = out + (long long)u * COUT * H * W + (long long)y * W + xx;
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) ou[(long long)o * H * W] = fma_row_get<COUT>(acc2, accr, o);
+            for (int q = 0; q < 8; ++q) {
+                const int e = e0 + tid + 256 * q;
+                if (e < n_el) tile[e] = v[q];
+            }
+        }
+        __syncthreads();
+        for (int c = 0; c < nc; ++c) {
+            const float* tc = tile + c * IT * ITW + py * ITW + px;
+#pragma unroll
+            for (int a = 0; a < KS; ++a)
+#pragma unroll
+                for (int b = 0; b < KS; ++b) {
+                    const float* __restrict__ wt = wu + ((long long)(c0 + c) * KS * KS + a * KS + b) * COUT;
+#pragma unroll
+                    for (int j = 0; j < NPX; ++j) fma_row<COUT>(wt, tc[a * ITW + b + RT * j], acc2[j], accr[j]);
+                }
+        }
     }
+    const int y = ty0 + py;
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+        const int xx = tx0 + px + RT * j;
+        if (y < H && xx < W) {
+            float* ou = out + (long long)u * COUT * H * W + (long long)y * W + xx;
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) ou[(long long)o * H * W] = fma_row_get<COUT>(acc2[j], accr[j], o);
+        }
+    }
+}
+
+template <int KS, int COUT, bool ZERO, int NPX>
+int launch_npx(const float* x, const float* w, const float* bias, int U, int Cin, int H, int W, bool shared, float* out,
+               hipStream_t st) {
+    const int tiles_x = ceil_div(W, RT * NPX), tiles = tiles_x * ceil_div(H, RT);
+    const size_t shmem = (size_t)std::min(Cin, NPX > 1 ? CK2 : CK) * (RT + KS - 1) * (RT * NPX + KS - 1) * sizeof(float);
+    if (shmem > 64 * 1024)
+        KMSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_reflect_kernel<KS, COUT, ZERO, NPX>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    conv_reflect_kernel<KS, COUT, ZERO, NPX><<<U * tiles, 256, shmem, st>>>(x, w, bias, out, Cin, H, W, tiles_x, tiles,
+                                                                            shared ? 0ll : (long long)Cin * KS * KS * COUT);
+    KMSR_HIP_CHECK(hipGetLastError());
+    return KMSR_OK;
 }
 
 template <int KS, int COUT, bool ZERO>
 int launch(const float* x, const float* w, const float* bias, int U, int Cin, int H, int W, bool shared, float* out,
            hipStream_t st) {
-    const int tiles_x = ceil_div(W, RT), tiles = tiles_x * ceil_div(H, RT);
-    const size_t shmem = (size_t)Cin * (RT + KS - 1) * (RT + KS - 1) * sizeof(float);
-    if (shmem > 64 * 1024)
-        KMSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_reflect_kernel<KS, COUT, ZERO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    conv_reflect_kernel<KS, COUT, ZERO><<<U * tiles, 256, shmem, st>>>(x, w, bias, out, Cin, H, W, tiles_x, tiles,
-                                                                       shared ? 0ll : (long long)Cin * KS * KS * COUT);
-    KMSR_HIP_CHECK(hipGetLastError());
-    return KMSR_OK;
+    // the 32 -> 32 layers (per-unit weights far beyond the scalar cache) take two pixels per thread
+    if constexpr (COUT == 32 && KS > 1) {
+        if (Cin >= CK2 && W > RT) return launch_npx<KS, COUT, ZERO, 2>(x, w, bias, U, Cin, H, W, shared, out, st);
+    }
+    return launch_npx<KS, COUT, ZERO, 1>(x, w, bias, U, Cin, H, W, shared, out, st);
 }
 
 int convk_forward(const kmsr_convk_desc* d, const float* x, const float* w, const float* bias, float* out, hipStream_t st) {

@@ -77,7 +77,8 @@ def convk_forward(x, w, k, pad="reflect", bias=None):
 
 
 def convk_dgrad(dy, w, k, pad="reflect"):
-    """Adjoint of convk_forward w.r.t. x: dy [U,Cout,H,W], w as in the forward -> dx [U,Cin,H,W]  (kmsr_convk_dgrad_f32)."""
+    """Adjoint of convk_forward w.r.t. x: dy [U,Cout,H,W], w as in the forward -> dx [U,Cin,H,W]  (kmsr_convk_dgrad_ws_f32:
+    with the scratch buffer the reflect-padded 32-channel layers run as a padded-domain pass plus a fold of the mirrored ring)."""
     lib = L.load()
     _on_gpu(dy, w)
     dy = dy.contiguous()
@@ -86,9 +87,11 @@ def convk_dgrad(dy, w, k, pad="reflect"):
     cin = w.shape[-3]
     wT = w.transpose(-1, -3).contiguous()                      # [.., Cout, k*k, Cin]
     dx = torch.empty((U, cin, H, W), device=dy.device, dtype=torch.float32)
+    desc = _convk_desc(U, cin, cout, H, W, k, pad, shared)
+    nb = int(lib.kmsr_convk_dgrad_workspace_bytes(desc))
+    ws = torch.empty(nb // 4, device=dy.device, dtype=torch.float32) if nb else None
     with torch.cuda.device(dy.device):
-        L.check(lib.kmsr_convk_dgrad_f32(_convk_desc(U, cin, cout, H, W, k, pad, shared), L.ptr(dy), L.ptr(wT), L.ptr(dx),
-                                         L.current_stream()))
+        L.check(lib.kmsr_convk_dgrad_ws_f32(desc, L.ptr(dy), L.ptr(wT), L.ptr(dx), L.ptr(ws), nb, L.current_stream()))
     return dx
 
 

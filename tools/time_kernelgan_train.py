@@ -30,7 +30,8 @@ print(f"single-kernel trainer iteration (batch 16, 80 chains @256^2): {ms:8.2f} 
 U = 40
 h = torch.rand(U, 32, 256, 256, device=dev); w = torch.rand(U, 32, 25, 32, device=dev) * 0.01; g = torch.rand(U, 32, 256, 256, device=dev)
 flops = 2.0 * U * 32 * 25 * 32 * 256 * 256
-for name, fn in (("fwd  ", lambda: kmsr_amd.convk_forward(h, w, 5)), ("dgrad", lambda: kmsr_amd.convk_dgrad(g, w, 5)),
-                 ("wgrad", lambda: kmsr_amd.convk_wgrad(h, g, 5))):
+for name, fn, how in (("fwd  ", lambda: kmsr_amd.convk_forward(h, w, 5), "packed fp32 VALU, 2 px / thread"),
+                      ("dgrad", lambda: kmsr_amd.convk_dgrad(g, w, 5), "padded-domain pass + fold"),
+                      ("wgrad", lambda: kmsr_amd.convk_wgrad(h, g, 5), "fp32 MFMA")):
     ms = timed(fn, 10)
-    print(f"convk {name} 5x5 32->32, 40 units @256^2: {ms:7.3f} ms  = {flops / ms / 1e9:6.1f} TFLOP/s (fp32 VALU)")
+    print(f"convk {name} 5x5 32->32, 40 units @256^2: {ms:7.3f} ms  = {flops / ms / 1e9:6.1f} TFLOP/s ({how})")
