@@ -45,6 +45,12 @@ __device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-
     return __builtin_bit_cast(unsigned short, b);
 }
 __device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+// two values -> one packed dword with ONE v_cvt_pk_bf16_f32 (two scalar casts cost cvt, cvt, shift, or)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
 
 // packed[cg][tap][co 64][Cin_p] bf16  <-  w[co][ci][tap] fp32
 // tf != 0: the data-gradient convolution's weights w'[ci][co][u][v] = w[co][ci][2-u][2-v] (the packed conv then maps the
@@ -266,6 +272,230 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_kernel(const unsigned sho
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Register-weight, double-buffered form of the kernel above (round 2; Cin <= 64).  The serial tile loop above pays two HBM round
+// trips per tile (input tile, residual) that nothing overlaps -- one workgroup of four waves per CU is all the 83 KB weight slab
+// leaves room for.  Here
+//   * every wave keeps ITS A operands -- the whole 64 x 9 x Cin slab, 16 B per lane and (tap, k-step, co half): 288 VGPRs at
+//     Cin = 64 -- in registers (one wave per SIMD owns all 512 VGPRs anyway), which frees the LDS for two input buffers plus a
+//     separate staging tile and halves the LDS operand traffic of the MFMA phase;
+//   * the NEXT item's halo tile travels HBM -> LDS by LDS-DMA while the current one is multiplied: the LDS image keeps the padded
+//     pixel pitch (Cin + 8 elements), every 9th 16-byte lane of the dense DMA stream is a pad lane with an out-of-range buffer offset (the hardware writes zeros), as
+//     do pixels outside the image;
+//   * the residual pieces are requested before the MFMA phase and consumed after it; two raw barriers per tile instead of four.
+// ------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int KS>
+struct RwGeo {
+    static constexpr int Cin = 16 * KS, CP = Cin + PADE, kvec = Cin / 8, UP = kvec + 1;     // 16-byte units per pixel incl. the pad unit
+    static constexpr int NPIX = BIH * BIW, NUNITS = NPIX * UP, NINSTR = (NUNITS + 63) / 64, NIW = (NINSTR + 3) / 4;
+    static constexpr int TILE_ELEMS = NIW * 4 * 64 * 8;                                     // bf16 elements of one input buffer
+    static constexpr int ST_ELEMS = (2 * BTH) * (2 * BTW) * (16 + PADE) > BTH * BTW * (BCO + PADE) ? (2 * BTH) * (2 * BTW) * (16 + PADE)
+                                                                                                  : BTH * BTW * (BCO + PADE);
+    static constexpr size_t LDS_BYTES = (size_t)(2 * TILE_ELEMS + ST_ELEMS) * 2 + BCO * sizeof(float);
+};
+
+template <bool PS, int KS, bool RELU>
+__global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned short* __restrict__ xg,
+                                                                 const unsigned short* __restrict__ wpk,
+                                                                 const float* __restrict__ bias,
+                                                                 const unsigned short* __restrict__ res,
+                                                                 unsigned short* __restrict__ out, Bf16Params p) {
+    using G = RwGeo<KS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];        // the ONLY LDS object: in0 | in1 | staging | bias
+    constexpr int Cin = G::Cin, CP = G::CP, kvec = G::kvec, UP = G::UP;
+    unsigned short* st = smem + 2 * G::TILE_ELEMS;
+    float* sbias = reinterpret_cast<float*>(st + G::ST_ELEMS);
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, W = p.W;
+    const int per_cg = p.N * p.tiles;
+
+    const int per = (p.n_items + (int)gridDim.x - 1) / (int)gridDim.x;
+    int item = blockIdx.x * per;
+    const int item_end = min(item + per, p.n_items);
+    if (item >= item_end) return;
+
+    // Lane constants of the DMA stream: unit uidx = i * 64 + lane is piece `uidx % UP` of tile pixel `uidx / UP` (piece kvec = the pad
+    // unit).  The loads are buffer loads: a lane whose pixel lies outside the image (or that is a pad / tail lane) gets an out-of-range
+    // offset and the hardware writes ZEROS to its LDS slot (tools/ubench/buffer_lds_oob.hip) -- the conv's zero padding for free.
+    int ur[G::NIW], uc[G::NIW], urel[G::NIW];
+#pragma unroll
+    for (int k = 0; k < G::NIW; ++k) {
+        const int uidx = (wv * G::NIW + k) * 64 + lane, pix = uidx / UP, piece = uidx - pix * UP, r = pix / BIW, c = pix - r * BIW;
+        const bool live = pix < G::NPIX && piece < kvec;
+        ur[k] = live ? r : -100000;                         // dead lanes fail the row check of every tile
+        uc[k] = c;
+        urel[k] = ((r - 1) * W + (c - 1)) * (Cin * 2) + 16 * piece;      // bytes from the tile's first OUTPUT pixel
+    }
+    auto issue_tile = [&](int it, int buf) {               // halo tile of item `it` -> input buffer `buf`, by LDS-DMA
+        const int rem = it % per_cg, n = rem / p.tiles, tile = rem % p.tiles;
+        const int ty0 = (tile / p.tiles_x) * BTH, tx0 = (tile % p.tiles_x) * BTW;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned short*>(xg + (long long)n * H * W * Cin), 0, (unsigned)(H * W * Cin * 2), 0x00020000);
+        const int tbase = (ty0 * W + tx0) * (Cin * 2);      // wave-uniform
+#pragma unroll
+        for (int k = 0; k < G::NIW; ++k) {
+            const int i = wv * G::NIW + k;                  // wave-uniform instruction index
+            if (i < G::NINSTR) {
+                const bool ok = (unsigned)(ty0 - 1 + ur[k]) < (unsigned)H && (unsigned)(tx0 - 1 + uc[k]) < (unsigned)W;
+                const unsigned off = ok ? (unsigned)(tbase + urel[k]) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + buf * G::TILE_ELEMS + i * 512), 16, off, 0, 0, 0);
+            }
+        }
+    };
+
+    bf16x8 areg[9][KS][2];
+    int cur_cg = -1, buf = 0;
+    issue_tile(item, 0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0);                          // the first tile (every later one is waited for before the stores of its predecessor)
+    for (; item < item_end; ++item, buf ^= 1) {
+        const int cg = item / per_cg, rem = item % per_cg, n = rem / p.tiles, tile = rem % p.tiles;
+        const int ty0 = (tile / p.tiles_x) * BTH, tx0 = (tile % p.tiles_x) * BTW;
+        if (cg != cur_cg) {                                 // this output group's weights -> registers, bias -> LDS
+            const unsigned short* __restrict__ wsrc = wpk + (long long)cg * 9 * BCO * Cin + (long long)l32 * Cin + 8 * half;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        areg[tap][ks][mt] = *reinterpret_cast<const bf16x8*>(wsrc + (tap * BCO + 32 * mt) * Cin + 16 * ks);
+        }
+        // No vmcnt wait here: this item's tile was waited for before the previous item's stores went out (below), so those stores
+        // -- which count on vmcnt too -- retire under this item's MFMA phase instead of stalling its start.
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): every LDS read of the previous item retired
+        if (cg != cur_cg) {
+            if (cur_cg >= 0) __builtin_amdgcn_s_barrier();  // previous item's bias readers are done
+            if (tid < BCO) sbias[tid] = (bias && cg * BCO + tid < p.Cout) ? bias[cg * BCO + tid] : 0.f;
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            cur_cg = cg;
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (item + 1 < item_end) issue_tile(item + 1, buf ^ 1);      // that buffer's readers finished before the barrier above
+
+        // residual / store addresses; the residual pieces are in flight during the MFMA phase
+        constexpr int NST = BTH * BTW * 8 / 256;
+        int go[NST];                                        // element offsets from the tile's first pixel (32-bit: a tile spans < 2^31)
+        bool ok[NST];
+        u32x4 rv[NST];
+        const long long tile_base = (((long long)n * H + ty0) * W + tx0) * p.Cout + cg * BCO;      // wave-uniform
+        if constexpr (!PS) {
+            const int pieces = min(BCO, p.Cout - cg * BCO) / 8;
+#pragma unroll
+            for (int t = 0; t < NST; ++t) {
+                const int e = tid + 256 * t;
+                const int piece = e & 7, pix = e >> 3, r = pix / BTW, c = pix % BTW;
+                ok[t] = piece < pieces && ty0 + r < H && tx0 + c < W;
+                go[t] = ok[t] ? (r * W + c) * p.Cout + 8 * piece : 0;
+                rv[t] = u32x4{0u, 0u, 0u, 0u};
+            }
+            if (res) {
+                const unsigned short* __restrict__ rb = res + tile_base;
+#pragma unroll
+                for (int t = 0; t < NST; ++t) rv[t] = *reinterpret_cast<const u32x4*>(rb + go[t]);
+            }
+        }
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+        const unsigned short* il = smem + buf * G::TILE_ELEMS;
+        const unsigned short* bp = il + ((2 * wv) * BIW + l32) * CP + 8 * half;       // + ((nt+dy)*BIW + dx)*CP + 16*ks
+        constexpr int NG = 9 * KS;
+        auto fetch_b = [&](int g, bf16x8& b0, bf16x8& b1) {
+            const int tap = g / KS, ks = g % KS, dy = tap / 3, dx = tap % 3;
+            b0 = *reinterpret_cast<const bf16x8*>(bp + (dy * BIW + dx) * CP + 16 * ks);
+            b1 = *reinterpret_cast<const bf16x8*>(bp + ((1 + dy) * BIW + dx) * CP + 16 * ks);
+        };
+        bf16x8 cb0, cb1;
+        fetch_b(0, cb0, cb1);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            bf16x8 nb0 = cb0, nb1 = cb1;
+            if (g + 1 < NG) fetch_b(g + 1, nb0, nb1);       // one group ahead: with one wave per SIMD nothing else covers an LDS round trip
+            asm volatile("" : "+v"(cb0), "+v"(cb1));
+            const int tap = g / KS, ks = g % KS;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[tap][ks][0], cb0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[tap][ks][0], cb1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[tap][ks][1], cb0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[tap][ks][1], cb1, acc[1][1], 0, 0, 0);
+            cb0 = nb0; cb1 = nb1;
+        }
+
+        // ---- epilogue into the staging tile (its own LDS region: no barrier before it -- the previous item's staging reads ended
+        //      before this item's first barrier).  Non-PS: st[(row*32 + col)][64 co].  PS: st[((2row+i)*64 + 2col+j)][16 c]
+        constexpr int SP = PS ? 16 + PADE : BCO + PADE;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int row = 2 * wv + nt;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co0 = mt * 32 + 8 * g + 4 * half;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[mt][nt][4 * g + r] + sbias[co0 + r];
+                        if constexpr (RELU) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    if constexpr (PS) {
+                        const int c = co0 >> 2;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            st[((2 * row + (r >> 1)) * (2 * BTW) + 2 * l32 + (r & 1)) * SP + c] = f2bf(v[r]);
+                    } else {
+                        *reinterpret_cast<uint2*>(st + (row * BTW + l32) * SP + co0) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    }
+                }
+            }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): staging complete
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0070);                 // vmcnt(0): the next tile (requested a whole MFMA phase ago) and the residual pieces
+        if constexpr (PS) {
+            const int Cq = p.Cout >> 2;
+            const int H2 = 2 * H, W2 = 2 * W;
+            for (int e = tid; e < (2 * BTH) * (2 * BTW) * 2; e += 256) {
+                const int piece = e & 1, pix = e >> 1, r = pix / (2 * BTW), c = pix % (2 * BTW);
+                const int oy = 2 * ty0 + r, ox = 2 * tx0 + c;
+                if (oy < H2 && ox < W2) {
+                    const u32x4 val = *reinterpret_cast<const u32x4*>(st + pix * SP + 8 * piece);
+                    *reinterpret_cast<u32x4*>(out + (((long long)n * H2 + oy) * W2 + ox) * Cq + cg * 16 + 8 * piece) = val;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NST; ++t) {
+                const int e = tid + 256 * t;
+                u32x4 val = *reinterpret_cast<const u32x4*>(st + (e >> 3) * SP + 8 * (e & 7));
+                if (res) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {           // low halves by a shift, high halves by a mask: 4 + 2 + 1 instructions per pair
+                        const float a0 = __builtin_bit_cast(float, val[q] << 16) + __builtin_bit_cast(float, rv[t][q] << 16);
+                        const float a1 = __builtin_bit_cast(float, val[q] & 0xffff0000u) + __builtin_bit_cast(float, rv[t][q] & 0xffff0000u);
+                        val[q] = pack2bf(a0, a1);
+                    }
+                }
+                if (ok[t]) *reinterpret_cast<u32x4*>(out + tile_base + go[t]) = val;
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0);
+}
+
 size_t bf16_lds_bytes(int Cin) {
     const int CP = Cin + PADE;
     return (size_t)(9 * BCO * CP + tile_region_elems(Cin)) * 2 + BCO * sizeof(float);
@@ -319,6 +549,8 @@ extern "C" int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x, 
         return fail(KMSR_E_BADARG, "bf16 conv: tensors must be 16-byte aligned");
     if (d->pixel_shuffle && residual) return fail(KMSR_E_BADARG, "residual is not supported together with pixel_shuffle");
     if (!x || !packed_w || !out) return fail(KMSR_E_BADARG, "null tensor pointer");
+    if ((long long)d->H * d->W * d->Cin * 2 >= (1ll << 31))
+        return fail(KMSR_E_UNSUPPORTED, "bf16 conv: one image must stay below 2 GiB (32-bit buffer offsets)");
     Bf16Params p{};
     p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.relu = d->relu;
     p.tiles_x = ceil_div(d->W, BTW);
@@ -328,7 +560,8 @@ extern "C" int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x, 
     if (items > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv grid too large");
     p.n_items = (int)items;
     const int grid = (int)std::min<long long>(items, 256);
-    const size_t shmem = bf16_lds_bytes(d->Cin);
+    const int ks = d->Cin / 16;
+    const size_t shmem = ks == 1 ? RwGeo<1>::LDS_BYTES : ks == 2 ? RwGeo<2>::LDS_BYTES : ks == 3 ? RwGeo<3>::LDS_BYTES : RwGeo<4>::LDS_BYTES;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const auto* xs = static_cast<const unsigned short*>(x);
     const auto* ws = static_cast<const unsigned short*>(packed_w);
@@ -340,15 +573,18 @@ extern "C" int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x, 
         return KMSR_OK;
     };
     int rc = KMSR_OK;
-    const int ks = d->Cin / 16;
-#define KMSR_BF16_LAUNCH(PS_)                                                                       \
+#define KMSR_BF16_LAUNCH(PS_, RL_)                                                                  \
     switch (ks) {                                                                                   \
-        case 1: rc = launch(conv3x3_bf16_kernel<PS_, 1>); break;                                    \
-        case 2: rc = launch(conv3x3_bf16_kernel<PS_, 2>); break;                                    \
-        case 3: rc = launch(conv3x3_bf16_kernel<PS_, 3>); break;                                    \
-        default: rc = launch(conv3x3_bf16_kernel<PS_, 4>); break;                                   \
+        case 1: rc = launch(conv3x3_bf16_rw_kernel<PS_, 1, RL_>); break;                            \
+        case 2: rc = launch(conv3x3_bf16_rw_kernel<PS_, 2, RL_>); break;                            \
+        case 3: rc = launch(conv3x3_bf16_rw_kernel<PS_, 3, RL_>); break;                            \
+        default: rc = launch(conv3x3_bf16_rw_kernel<PS_, 4, RL_>); break;                           \
     }
-    if (d->pixel_shuffle) { KMSR_BF16_LAUNCH(true) } else { KMSR_BF16_LAUNCH(false) }
+    if (d->pixel_shuffle) {
+        if (d->relu) { KMSR_BF16_LAUNCH(true, true) } else { KMSR_BF16_LAUNCH(true, false) }
+    } else {
+        if (d->relu) { KMSR_BF16_LAUNCH(false, true) } else { KMSR_BF16_LAUNCH(false, false) }
+    }
 #undef KMSR_BF16_LAUNCH
     if (rc != KMSR_OK) return rc;
     KMSR_HIP_CHECK(hipGetLastError());
