@@ -296,6 +296,8 @@ struct RwGeo {
     static constexpr size_t LDS_BYTES = (size_t)(2 * TILE_ELEMS + ST_ELEMS) * 2 + BCO * sizeof(float);
 };
 
+struct Origin { int n, ty0, tx0, cg; };      // image, tile origin and output-channel group of a work item
+
 template <bool PS, int KS, bool RELU>
 __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned short* __restrict__ xg,
                                                                  const unsigned short* __restrict__ wpk,
@@ -329,9 +331,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
         uc[k] = c;
         urel[k] = ((r - 1) * W + (c - 1)) * (Cin * 2) + 16 * piece;      // bytes from the tile's first OUTPUT pixel
     }
-    auto issue_tile = [&](int it, int buf) {               // halo tile of item `it` -> input buffer `buf`, by LDS-DMA
-        const int rem = it % per_cg, n = rem / p.tiles, tile = rem % p.tiles;
-        const int ty0 = (tile / p.tiles_x) * BTH, tx0 = (tile % p.tiles_x) * BTW;
+    auto issue_tile = [&](const Origin& o, int buf) {     // halo tile of the item at `o` -> input buffer `buf`, by LDS-DMA
+        const int n = o.n, ty0 = o.ty0, tx0 = o.tx0;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned short*>(xg + (long long)n * H * W * Cin), 0, (unsigned)(H * W * Cin * 2), 0x00020000);
         const int tbase = (ty0 * W + tx0) * (Cin * 2);      // wave-uniform
@@ -346,14 +347,56 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
         }
     };
 
+    // store / residual pieces of a thread: tile-invariant element offsets from the tile's first pixel (32-bit: a tile spans < 2^31)
+    constexpr int NST = BTH * BTW * 8 / 256;
+    int go[NST], sr[NST], sc[NST];
+#pragma unroll
+    for (int t = 0; t < NST; ++t) {
+        const int e = tid + 256 * t, pix = e >> 3;
+        sr[t] = pix / BTW;
+        sc[t] = pix % BTW;
+        go[t] = (sr[t] * W + sc[t]) * p.Cout + 8 * (e & 7);
+    }
+    auto tile_origin = [&](int it) {                        // a few scalar divisions: once per item, never per piece
+        Origin o;
+        o.cg = it / per_cg;
+        const int rem = it - o.cg * per_cg;
+        o.n = rem / p.tiles;
+        const int tile = rem - o.n * p.tiles;
+        o.ty0 = (tile / p.tiles_x) * BTH;
+        o.tx0 = (tile % p.tiles_x) * BTW;
+        return o;
+    };
+    // residual piece t of the item at `o` -> rv[t] (a piece outside the image or past the channel tail reads the tile's first piece instead)
+    u32x4 rv[NST];
+    auto residual_piece = [&](const Origin& o, const unsigned short* __restrict__ rb, int pieces, int t) {
+        const bool okp = ((tid + 256 * t) & 7) < pieces && o.ty0 + sr[t] < H && o.tx0 + sc[t] < W;
+        rv[t] = *reinterpret_cast<const u32x4*>(rb + (okp ? go[t] : 0));
+    };
+    auto residual_base = [&](const Origin& o) { return res + (((long long)o.n * H + o.ty0) * W + o.tx0) * p.Cout + o.cg * BCO; };
+
     bf16x8 areg[9][KS][2];
     int cur_cg = -1, buf = 0;
-    issue_tile(item, 0);
+    if constexpr (!PS) {
+        if (res) {
+            {
+                const Origin o = tile_origin(item);
+                const unsigned short* rb = residual_base(o);
+                const int pc = min(BCO, p.Cout - o.cg * BCO) / 8;
+#pragma unroll
+                for (int t = 0; t < NST; ++t) residual_piece(o, rb, pc, t);
+            }
+        }
+    }
+    Origin cur = tile_origin(item), nxt_carry = cur;
+    issue_tile(cur, 0);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0);                          // the first tile (every later one is waited for before the stores of its predecessor)
-    for (; item < item_end; ++item, buf ^= 1) {
-        const int cg = item / per_cg, rem = item % per_cg, n = rem / p.tiles, tile = rem % p.tiles;
-        const int ty0 = (tile / p.tiles_x) * BTH, tx0 = (tile % p.tiles_x) * BTW;
+    for (; item < item_end; ++item, buf ^= 1, cur = nxt_carry) {
+        const int cg = cur.cg, n = cur.n, ty0 = cur.ty0, tx0 = cur.tx0;
+        const bool more = item + 1 < item_end;
+        const Origin nxt = more ? tile_origin(item + 1) : cur;
+        nxt_carry = nxt;
         if (cg != cur_cg) {                                 // this output group's weights -> registers, bias -> LDS
             const unsigned short* __restrict__ wsrc = wpk + (long long)cg * 9 * BCO * Cin + (long long)l32 * Cin + 8 * half;
 #pragma unroll
@@ -377,30 +420,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (item + 1 < item_end) issue_tile(item + 1, buf ^ 1);      // that buffer's readers finished before the barrier above
+        if (more) issue_tile(nxt, buf ^ 1);                 // that buffer's readers finished before the barrier above
 
-        // residual / store addresses; the residual pieces are in flight during the MFMA phase
-        constexpr int NST = BTH * BTW * 8 / 256;
-        int go[NST];                                        // element offsets from the tile's first pixel (32-bit: a tile spans < 2^31)
-        bool ok[NST];
-        u32x4 rv[NST];
         const long long tile_base = (((long long)n * H + ty0) * W + tx0) * p.Cout + cg * BCO;      // wave-uniform
-        if constexpr (!PS) {
-            const int pieces = min(BCO, p.Cout - cg * BCO) / 8;
-#pragma unroll
-            for (int t = 0; t < NST; ++t) {
-                const int e = tid + 256 * t;
-                const int piece = e & 7, pix = e >> 3, r = pix / BTW, c = pix % BTW;
-                ok[t] = piece < pieces && ty0 + r < H && tx0 + c < W;
-                go[t] = ok[t] ? (r * W + c) * p.Cout + 8 * piece : 0;
-                rv[t] = u32x4{0u, 0u, 0u, 0u};
-            }
-            if (res) {
-                const unsigned short* __restrict__ rb = res + tile_base;
-#pragma unroll
-                for (int t = 0; t < NST; ++t) rv[t] = *reinterpret_cast<const u32x4*>(rb + go[t]);
-            }
-        }
 
         f32x16 acc[2][2];
 #pragma unroll
@@ -476,9 +498,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
                 }
             }
         } else {
+            const int pieces = min(BCO, p.Cout - cg * BCO) / 8, npc = min(BCO, p.Cout - nxt.cg * BCO) / 8;
+            const unsigned short* nrb = res ? residual_base(nxt) : nullptr;
 #pragma unroll
             for (int t = 0; t < NST; ++t) {
                 const int e = tid + 256 * t;
+                const bool okt = (e & 7) < pieces && ty0 + sr[t] < H && tx0 + sc[t] < W;
                 u32x4 val = *reinterpret_cast<const u32x4*>(st + (e >> 3) * SP + 8 * (e & 7));
                 if (res) {
 #pragma unroll
@@ -488,7 +513,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
                         val[q] = pack2bf(a0, a1);
                     }
                 }
-                if (ok[t]) *reinterpret_cast<u32x4*>(out + tile_base + go[t]) = val;
+                if (okt) *reinterpret_cast<u32x4*>(out + tile_base + go[t]) = val;
+                // the NEXT item's residual piece takes the register this one just freed: it is in flight across the loop edge, so the
+                // memory pipe has work while this workgroup stores and sets up its next tile
+                if (res && more) residual_piece(nxt, nrb, npc, t);
             }
         }
     }
