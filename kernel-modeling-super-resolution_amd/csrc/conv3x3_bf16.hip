@@ -333,15 +333,16 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
     }
     auto issue_tile = [&](const Origin& o, int buf) {     // halo tile of the item at `o` -> input buffer `buf`, by LDS-DMA
         const int n = o.n, ty0 = o.ty0, tx0 = o.tx0;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned short*>(xg + (long long)n * H * W * Cin), 0, (unsigned)(H * W * Cin * 2), 0x00020000);
-        const int tbase = (ty0 * W + tx0) * (Cin * 2);      // wave-uniform
+        const unsigned nrec = (unsigned)H * (unsigned)W * (unsigned)(Cin * 2);       // bytes of one image (< 4 GiB, host-checked)
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xg + (long long)n * H * W * Cin), 0, nrec, 0x00020000);
+        const unsigned tbase = ((unsigned)ty0 * (unsigned)W + (unsigned)tx0) * (unsigned)(Cin * 2);      // wave-uniform
 #pragma unroll
         for (int k = 0; k < G::NIW; ++k) {
             const int i = wv * G::NIW + k;                  // wave-uniform instruction index
             if (i < G::NINSTR) {
                 const bool ok = (unsigned)(ty0 - 1 + ur[k]) < (unsigned)H && (unsigned)(tx0 - 1 + uc[k]) < (unsigned)W;
-                const unsigned off = ok ? (unsigned)(tbase + urel[k]) : 0x80000000u;
+                const unsigned off = ok ? tbase + (unsigned)urel[k] : nrec;      // modulo-2^32 sum; nrec itself is out of range
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + buf * G::TILE_ELEMS + i * 512), 16, off, 0, 0, 0);
             }
         }
@@ -577,8 +578,8 @@ extern "C" int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x, 
         return fail(KMSR_E_BADARG, "bf16 conv: tensors must be 16-byte aligned");
     if (d->pixel_shuffle && residual) return fail(KMSR_E_BADARG, "residual is not supported together with pixel_shuffle");
     if (!x || !packed_w || !out) return fail(KMSR_E_BADARG, "null tensor pointer");
-    if ((long long)d->H * d->W * d->Cin * 2 >= (1ll << 31))
-        return fail(KMSR_E_UNSUPPORTED, "bf16 conv: one image must stay below 2 GiB (32-bit buffer offsets)");
+    if ((long long)d->H * d->W * d->Cin * 2 > 0xFFFFFFF0ll)
+        return fail(KMSR_E_UNSUPPORTED, "bf16 conv: one image must stay below 4 GiB (32-bit buffer offsets)");
     Bf16Params p{};
     p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.relu = d->relu;
     p.tiles_x = ceil_div(d->W, BTW);

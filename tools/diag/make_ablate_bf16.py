@@ -21,11 +21,9 @@ def build(name, edits):
     print("built", name)
 NOMFMA = [("        for (int g = 0; g < NG; ++g) {\n            bf16x8 nb0 = cb0, nb1 = cb1;\n            if (g + 1 < NG) fetch_b(g + 1, nb0, nb1);       // one group ahead",
            "        for (int g = 0; g < (p.H == 12345 ? NG : 1); ++g) {\n            bf16x8 nb0 = cb0, nb1 = cb1;\n            if (g + 1 < NG) fetch_b(g + 1, nb0, nb1);       // one group ahead")]
-NODMA = [("        if (item + 1 < item_end) issue_tile(item + 1, buf ^ 1);      // that buffer's readers", "        if (item + 1 < item_end && p.H == 12345) issue_tile(item + 1, buf ^ 1);      // that buffer's readers")]
-NOSTORE = [("                if (ok[t]) *reinterpret_cast<u32x4*>(out + go[t]) = val;\n            }\n        }\n    }\n    asm volatile(\"\" ::: \"memory\");\n    __builtin_amdgcn_s_waitcnt(0);",
-            "                if (ok[t] && (p.H == 12345 || val[0] == 0x12345678u)) *reinterpret_cast<u32x4*>(out + go[t]) = val;\n            }\n        }\n    }\n    asm volatile(\"\" ::: \"memory\");\n    __builtin_amdgcn_s_waitcnt(0);")]
-NORES = [("            if (res) {\n#pragma unroll\n                for (int t = 0; t < NST; ++t) rv[t] = *reinterpret_cast<const u32x4*>(res + go[t]);\n            }\n        }\n\n        f32x16 acc[2][2];",
-          "            if (res && p.H == 12345) {\n#pragma unroll\n                for (int t = 0; t < NST; ++t) rv[t] = *reinterpret_cast<const u32x4*>(res + go[t]);\n            }\n        }\n\n        f32x16 acc[2][2];")]
+NODMA = [("        if (more) issue_tile(nxt, buf ^ 1);                 // that buffer's readers", "        if (more && p.H == 12345) issue_tile(nxt, buf ^ 1);                 // that buffer's readers")]
+NOSTORE = [("                if (okt) *reinterpret_cast<u32x4*>(out + tile_base + go[t]) = val;", "                if (okt && (p.H == 12345 || val[0] == 0x12345678u)) *reinterpret_cast<u32x4*>(out + tile_base + go[t]) = val;")]
+NORES = [("                if (res && more) residual_piece(nxt, nrb, npc, t);", "                if (res && more && p.H == 12345) residual_piece(nxt, nrb, npc, t);")]
 ABL = {"nomfma": NOMFMA, "nodma": NODMA, "nostore": NOSTORE, "nores": NORES, "nodma_nostore_nores": NODMA + NOSTORE + NORES}
 for n in (sys.argv[1:] or ABL):
     build(n, ABL[n])
