@@ -21,6 +21,7 @@ namespace {
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int BTH = 8, BTW = 32;          // output tile (rows x cols)
 constexpr int BIH = BTH + 2, BIW = BTW + 2;
@@ -298,7 +299,8 @@ struct RwGeo {
 
 struct Origin { int n, ty0, tx0, cg; };      // image, tile origin and output-channel group of a work item
 
-template <bool PS, int KS, bool RELU>
+// MT = 32-channel output blocks actually computed (1 for layers with <= 32 output channels, e.g. the 7-band tail: half the MFMAs)
+template <bool PS, int KS, bool RELU, int MT>
 __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned short* __restrict__ xg,
                                                                  const unsigned short* __restrict__ wpk,
                                                                  const float* __restrict__ bias,
@@ -376,19 +378,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
     };
     auto residual_base = [&](const Origin& o) { return res + (((long long)o.n * H + o.ty0) * W + o.tx0) * p.Cout + o.cg * BCO; };
 
-    bf16x8 areg[9][KS][2];
+    bf16x8 areg[9][KS][MT];
     int cur_cg = -1, buf = 0;
-    if constexpr (!PS) {
-        if (res) {
-            {
-                const Origin o = tile_origin(item);
-                const unsigned short* rb = residual_base(o);
-                const int pc = min(BCO, p.Cout - o.cg * BCO) / 8;
-#pragma unroll
-                for (int t = 0; t < NST; ++t) residual_piece(o, rb, pc, t);
-            }
-        }
-    }
     Origin cur = tile_origin(item), nxt_carry = cur;
     issue_tile(cur, 0);
     asm volatile("" ::: "memory");
@@ -399,13 +390,17 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
         const Origin nxt = more ? tile_origin(item + 1) : cur;
         nxt_carry = nxt;
         if (cg != cur_cg) {                                 // this output group's weights -> registers, bias -> LDS
-            const unsigned short* __restrict__ wsrc = wpk + (long long)cg * 9 * BCO * Cin + (long long)l32 * Cin + 8 * half;
+            // PixelShuffle: MFMA row i = 8g + 4h + r of a 32-row block multiplies with the weights of conv channel 16h + 4r + g, so
+            // that a lane's 4 consecutive accumulators are 4 ADJACENT shuffled channels (c = 4h + r) of ONE sub-pixel (g = 2i + j):
+            // one 8-byte staging write per group instead of four 2-byte ones
+            const int arow = PS ? 16 * ((l32 >> 2) & 1) + 4 * (l32 & 3) + (l32 >> 3) : l32;
+            const unsigned short* __restrict__ wsrc = wpk + (long long)cg * 9 * BCO * Cin + (long long)arow * Cin + 8 * half;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
+                    for (int mt = 0; mt < MT; ++mt)
                         areg[tap][ks][mt] = *reinterpret_cast<const bf16x8*>(wsrc + (tap * BCO + 32 * mt) * Cin + 16 * ks);
         }
         // No vmcnt wait here: this item's tile was waited for before the previous item's stores went out (below), so those stores
@@ -422,12 +417,20 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (more) issue_tile(nxt, buf ^ 1);                 // that buffer's readers finished before the barrier above
+        if constexpr (!PS) {
+            if (res) {                                      // this item's residual pieces: in flight during the MFMA phase
+                const unsigned short* rb = residual_base(cur);
+                const int pc = min(BCO, p.Cout - cg * BCO) / 8;
+#pragma unroll
+                for (int t = 0; t < NST; ++t) residual_piece(cur, rb, pc, t);
+            }
+        }
 
         const long long tile_base = (((long long)n * H + ty0) * W + tx0) * p.Cout + cg * BCO;      // wave-uniform
 
-        f32x16 acc[2][2];
+        f32x16 acc[MT][2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -448,18 +451,35 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
             if (g + 1 < NG) fetch_b(g + 1, nb0, nb1);       // one group ahead: with one wave per SIMD nothing else covers an LDS round trip
             asm volatile("" : "+v"(cb0), "+v"(cb1));
             const int tap = g / KS, ks = g % KS;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[tap][ks][0], cb0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[tap][ks][0], cb1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[tap][ks][1], cb0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[tap][ks][1], cb1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[tap][ks][mt], cb0, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[tap][ks][mt], cb1, acc[mt][1], 0, 0, 0);
+            }
             cb0 = nb0; cb1 = nb1;
         }
 
         // ---- epilogue into the staging tile (its own LDS region: no barrier before it -- the previous item's staging reads ended
         //      before this item's first barrier).  Non-PS: st[(row*32 + col)][64 co].  PS: st[((2row+i)*64 + 2col+j)][16 c]
         constexpr int SP = PS ? 16 + PADE : BCO + PADE;
+        // the 32 bias values of this lane in ONE batch of LDS reads (cycle stamps, tools/diag/make_stamped_bf16.py: read -> wait ->
+        // add per group of 4 channels exposed the LDS latency 16 times, 1900 cycles for 170 instructions)
+        f32x4 bv[MT][4];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (PS) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bv[mt][g][r] = sbias[mt * 32 + 16 * half + 4 * r + g];
+                } else {
+                    bv[mt][g] = *reinterpret_cast<const f32x4*>(sbias + mt * 32 + 8 * g + 4 * half);
+                }
+            }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(bv[mt][0]), "+v"(bv[mt][1]), "+v"(bv[mt][2]), "+v"(bv[mt][3]));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int row = 2 * wv + nt;
@@ -469,14 +489,13 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        v[r] = acc[mt][nt][4 * g + r] + sbias[co0 + r];
+                        v[r] = acc[mt][nt][4 * g + r] + bv[mt][g][r];
                         if constexpr (RELU) v[r] = fmaxf(v[r], 0.f);
                     }
                     if constexpr (PS) {
-                        const int c = co0 >> 2;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            st[((2 * row + (r >> 1)) * (2 * BTW) + 2 * l32 + (r & 1)) * SP + c] = f2bf(v[r]);
+                        // shuffled channels c = 8 mt + 4 half + r of sub-pixel (i, j) = (g >> 1, g & 1)
+                        *reinterpret_cast<uint2*>(st + ((2 * row + (g >> 1)) * (2 * BTW) + 2 * l32 + (g & 1)) * SP + 8 * mt + 4 * half) =
+                            make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                     } else {
                         *reinterpret_cast<uint2*>(st + (row * BTW + l32) * SP + co0) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                     }
@@ -490,34 +509,46 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
         if constexpr (PS) {
             const int Cq = p.Cout >> 2;
             const int H2 = 2 * H, W2 = 2 * W;
-            for (int e = tid; e < (2 * BTH) * (2 * BTW) * 2; e += 256) {
+            constexpr int NPS = (2 * BTH) * (2 * BTW) * 2 / 256;    // 8 pieces per thread: all staging reads first, then the stores
+            u32x4 val[NPS];
+#pragma unroll
+            for (int t = 0; t < NPS; ++t) {
+                const int e = tid + 256 * t;
+                val[t] = *reinterpret_cast<const u32x4*>(st + (e >> 1) * SP + 8 * (e & 1));
+            }
+            asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]));
+            unsigned short* ob = out + (((long long)n * H2 + 2 * ty0) * W2 + 2 * tx0) * Cq + cg * 16;      // wave-uniform
+#pragma unroll
+            for (int t = 0; t < NPS; ++t) {
+                const int e = tid + 256 * t;
                 const int piece = e & 1, pix = e >> 1, r = pix / (2 * BTW), c = pix % (2 * BTW);
-                const int oy = 2 * ty0 + r, ox = 2 * tx0 + c;
-                if (oy < H2 && ox < W2) {
-                    const u32x4 val = *reinterpret_cast<const u32x4*>(st + pix * SP + 8 * piece);
-                    *reinterpret_cast<u32x4*>(out + (((long long)n * H2 + oy) * W2 + ox) * Cq + cg * 16 + 8 * piece) = val;
-                }
+                if (2 * ty0 + r < H2 && 2 * tx0 + c < W2) *reinterpret_cast<u32x4*>(ob + (r * W2 + c) * Cq + 8 * piece) = val[t];
             }
         } else {
-            const int pieces = min(BCO, p.Cout - cg * BCO) / 8, npc = min(BCO, p.Cout - nxt.cg * BCO) / 8;
-            const unsigned short* nrb = res ? residual_base(nxt) : nullptr;
+            const int pieces = min(BCO, p.Cout - cg * BCO) / 8;
+            // batches (stamps: one piece at a time -- LDS read, wait, add, store -- took 2100 cycles without and 4000 with the residual):
+            // all staging reads, then the residual adds, then the stores, then the next item's residual requests
+            u32x4 val[NST];
 #pragma unroll
             for (int t = 0; t < NST; ++t) {
                 const int e = tid + 256 * t;
-                const bool okt = (e & 7) < pieces && ty0 + sr[t] < H && tx0 + sc[t] < W;
-                u32x4 val = *reinterpret_cast<const u32x4*>(st + (e >> 3) * SP + 8 * (e & 7));
-                if (res) {
+                val[t] = *reinterpret_cast<const u32x4*>(st + (e >> 3) * SP + 8 * (e & 7));
+            }
+            asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]));
+            if (res) {
+#pragma unroll
+                for (int t = 0; t < NST; ++t)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {           // low halves by a shift, high halves by a mask: 4 + 2 + 1 instructions per pair
-                        const float a0 = __builtin_bit_cast(float, val[q] << 16) + __builtin_bit_cast(float, rv[t][q] << 16);
-                        const float a1 = __builtin_bit_cast(float, val[q] & 0xffff0000u) + __builtin_bit_cast(float, rv[t][q] & 0xffff0000u);
-                        val[q] = pack2bf(a0, a1);
+                        const float a0 = __builtin_bit_cast(float, val[t][q] << 16) + __builtin_bit_cast(float, rv[t][q] << 16);
+                        const float a1 = __builtin_bit_cast(float, val[t][q] & 0xffff0000u) + __builtin_bit_cast(float, rv[t][q] & 0xffff0000u);
+                        val[t][q] = pack2bf(a0, a1);
                     }
-                }
-                if (okt) *reinterpret_cast<u32x4*>(out + tile_base + go[t]) = val;
-                // the NEXT item's residual piece takes the register this one just freed: it is in flight across the loop edge, so the
-                // memory pipe has work while this workgroup stores and sets up its next tile
-                if (res && more) residual_piece(nxt, nrb, npc, t);
+            }
+#pragma unroll
+            for (int t = 0; t < NST; ++t) {
+                const bool okt = ((tid + 256 * t) & 7) < pieces && ty0 + sr[t] < H && tx0 + sc[t] < W;
+                if (okt) *reinterpret_cast<u32x4*>(out + tile_base + go[t]) = val[t];
             }
         }
     }
@@ -602,17 +633,19 @@ extern "C" int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x, 
         return KMSR_OK;
     };
     int rc = KMSR_OK;
-#define KMSR_BF16_LAUNCH(PS_, RL_)                                                                  \
+#define KMSR_BF16_LAUNCH(PS_, RL_, MT_)                                                             \
     switch (ks) {                                                                                   \
-        case 1: rc = launch(conv3x3_bf16_rw_kernel<PS_, 1, RL_>); break;                            \
-        case 2: rc = launch(conv3x3_bf16_rw_kernel<PS_, 2, RL_>); break;                            \
-        case 3: rc = launch(conv3x3_bf16_rw_kernel<PS_, 3, RL_>); break;                            \
-        default: rc = launch(conv3x3_bf16_rw_kernel<PS_, 4, RL_>); break;                           \
+        case 1: rc = launch(conv3x3_bf16_rw_kernel<PS_, 1, RL_, MT_>); break;                       \
+        case 2: rc = launch(conv3x3_bf16_rw_kernel<PS_, 2, RL_, MT_>); break;                       \
+        case 3: rc = launch(conv3x3_bf16_rw_kernel<PS_, 3, RL_, MT_>); break;                       \
+        default: rc = launch(conv3x3_bf16_rw_kernel<PS_, 4, RL_, MT_>); break;                      \
     }
     if (d->pixel_shuffle) {
-        if (d->relu) { KMSR_BF16_LAUNCH(true, true) } else { KMSR_BF16_LAUNCH(true, false) }
+        if (d->relu) { KMSR_BF16_LAUNCH(true, true, 2) } else { KMSR_BF16_LAUNCH(true, false, 2) }
+    } else if (d->Cout <= 32) {                     // one 32-channel block is enough (the 7-band tail: Cout_p = 16)
+        if (d->relu) { KMSR_BF16_LAUNCH(false, true, 1) } else { KMSR_BF16_LAUNCH(false, false, 1) }
     } else {
-        if (d->relu) { KMSR_BF16_LAUNCH(false, true) } else { KMSR_BF16_LAUNCH(false, false) }
+        if (d->relu) { KMSR_BF16_LAUNCH(false, true, 2) } else { KMSR_BF16_LAUNCH(false, false, 2) }
     }
 #undef KMSR_BF16_LAUNCH
     if (rc != KMSR_OK) return rc;
