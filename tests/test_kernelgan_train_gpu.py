@@ -73,6 +73,11 @@ CASES = [  # (k, Cin, Cout, pad, shared, bias, U, H, W)
     (1, 64, 64, "zero", True, True, 2, 20, 17),
     (1, 64, 1, "zero", True, True, 2, 32, 32),
     (7, 1, 32, "zero", False, False, 2, 18, 18),
+    # the 32 -> 32 paths of round 2: MFMA weight gradient (k*k = 9 and 1 column tiles), padded-domain + fold data gradient,
+    # two pixels per thread in the forward / zero-padded data gradient, shared weights summed over units
+    (3, 32, 32, "reflect", False, False, 2, 40, 64),
+    (5, 32, 32, "zero", True, True, 2, 33, 70),
+    (1, 32, 32, "reflect", False, False, 2, 17, 40),
 ]
 
 
