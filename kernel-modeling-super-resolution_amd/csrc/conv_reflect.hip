@@ -1,8 +1,9 @@
 // Small-channel k x k convolution with reflect (or zero) padding and per-unit (or shared) weights -- forward leg
 // (semantics: include/kmsr.h; the data / weight gradient legs are in convk_bwd.hip).
-// One workgroup = one 16x16 output tile of one unit; the reflect-padded input tile of ALL input channels sits in LDS
-// (<= 32 x 22 x 22 floats), each thread owns one pixel and all COUT output channels; weights are wave-uniform
-// ([ci][tap][co] contiguous per unit) so they arrive through the scalar cache and feed v_fmac as SGPR operands.
+// One workgroup = one 16 x 16 (or 16 x 32: two pixels per thread, the 32 -> 32 layers) output tile of one unit; the reflect-padded
+// input tile sits in LDS (all input channels, or chunks of 8 for the wide tile), each thread owns its pixel(s) and all COUT output
+// channels as v_pk_fma_f32 pairs; weights are wave-uniform ([ci][tap][co] contiguous per unit) so they arrive through the scalar
+// cache and feed the FMAs as SGPR operands.
 #include "kmsr_common.h"
 
 #include <algorithm>

@@ -5,8 +5,10 @@
 //   wgrad: dw[ci,tap,co] = sum_pixels dy[co,p] * xpad[ci,p+tap].  Per (unit, strip) workgroup: x tile (padded) and the dy
 //          tile ([pixel][co], co fastest) in LDS; a thread owns NU (ci,tap) pairs x CB consecutive co and walks the 256
 //          pixels of a tile with 1 b32 + CB/4 b128 LDS reads per CB FMAs.  Strip partials are summed in a fixed order.
-// Thread-per-pixel / thread-per-output VALU code: these layers have 1..64 channels (KernelGAN generator chains and the
-// patch critic), far below an MFMA tile.
+//          With scratch memory the 32-channel reflect layers run as a zero-padded pass on the padded domain + convk_fold_kernel.
+// Thread-per-pixel / thread-per-output VALU code (weights as SGPR operands) for the 1..5- and 64-channel layers of the KernelGAN
+// generator chains and the patch critic; the 32 -> 32 layers' weight gradient is a per-unit GEMM on the matrix pipe
+// (convk_wgrad_mfma_kernel).  Numbers: profiles/r02_n1_kernelgan_trainer_timing.log.
 #include <algorithm>
 
 #include "kmsr_common.h"
