@@ -10,7 +10,7 @@ from bench import DegradeWorkload
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 mode = sys.argv[1] if len(sys.argv) > 1 else "vb"
-wl = DegradeWorkload(dev, 0)
+wl = DegradeWorkload(dev, 0, batch=int(os.environ.get("KMSR_TUNE_B", 32)), C=int(os.environ.get("KMSR_TUNE_C", 5)))   # about config 2 (48 planes): B=10 C=5 (the bank has 5 bands)
 variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "4,8,16,32,64".split(","))]
 def run(rows):
     if mode == "vb":
