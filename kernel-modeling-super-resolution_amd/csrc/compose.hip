@@ -12,6 +12,7 @@
 #include "kmsr_common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace kmsr {
 namespace {
@@ -93,33 +94,53 @@ __global__ void __launch_bounds__(256) compose_kernels_kernel(const float* __res
                 const float* __restrict__ arow = wl + (long long)l32 * KT + half;      // row o of W, skewed by h
                 const int* trow = tab + half * (KT >> 1);
                 const int nblk = KT >> 5;                                              // blocks of 8 chunks = 32 kk (ci = 32: 8 k^2 chunks)
-                f32x4 av[2][8];
+                // One block = 32 kk = 16 MFMA steps per tile.  All operand requests of a block go out before its first MFMA (the
+                // offset table, then the 16 x T im2col samples; the next block's weight pieces are already in flight): written
+                // step by step hipcc waits for each ds_read_b32 right before its MFMA and the LDS latency is paid per step.
+                auto run = [&](auto TT) {
+                    constexpr int T = decltype(TT)::value;
+                    f32x4 av[2][8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) av[0][c] = *reinterpret_cast<const f32x4_u*>(arow + 4 * c);
-                for (int blk = 0; blk < nblk; blk += 2) {
+                    for (int c = 0; c < 8; ++c) av[0][c] = *reinterpret_cast<const f32x4_u*>(arow + 4 * c);
+                    for (int blk = 0; blk < nblk; blk += 2) {
 #pragma unroll
-                    for (int ph = 0; ph < 2; ++ph) {                                   // phase ph computes av[ph] while av[ph ^ 1] loads
-                        const int bk = blk + ph;
-                        if (bk < nblk) {
-                            if (bk + 1 < nblk) {
+                        for (int ph = 0; ph < 2; ++ph) {                               // phase ph computes av[ph] while av[ph ^ 1] loads
+                            const int bk = blk + ph;
+                            if (bk < nblk) {
+                                if (bk + 1 < nblk) {
 #pragma unroll
-                                for (int c = 0; c < 8; ++c)
-                                    av[ph ^ 1][c] = *reinterpret_cast<const f32x4_u*>(arow + 32 * (bk + 1) + 4 * c);
-                            }
+                                    for (int c = 0; c < 8; ++c)
+                                        av[ph ^ 1][c] = *reinterpret_cast<const f32x4_u*>(arow + 32 * (bk + 1) + 4 * c);
+                                }
+                                i32x4 o4[4];
 #pragma unroll
-                            for (int c4 = 0; c4 < 4; ++c4) {                           // 4 table entries = 4 steps = 2 chunks
-                                const i32x4 o4 = *reinterpret_cast<const i32x4*>(trow + 16 * bk + 4 * c4);
-                                const int off[4] = {o4.x, o4.y, o4.z, o4.w};
-                                const float as[4] = {av[ph][2 * c4].x, av[ph][2 * c4].z, av[ph][2 * c4 + 1].x, av[ph][2 * c4 + 1].z};
+                                for (int c4 = 0; c4 < 4; ++c4) o4[c4] = *reinterpret_cast<const i32x4*>(trow + 16 * bk + 4 * c4);
+                                float bs[T][16];
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[q], cur[base[0] + off[q]], acc[0], 0, 0, 0);
-                                    if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[q], cur[base[1] + off[q]], acc[1], 0, 0, 0);
+                                for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                        for (int t = 0; t < T; ++t) bs[t][4 * c4 + q] = cur[base[t] + o4[c4][q]];
+#pragma unroll
+                                for (int t = 0; t < T; ++t)
+#pragma unroll
+                                    for (int e = 0; e < 16; e += 4) asm volatile("" : "+v"(bs[t][e]), "+v"(bs[t][e + 1]), "+v"(bs[t][e + 2]), "+v"(bs[t][e + 3]));
+#pragma unroll
+                                for (int c4 = 0; c4 < 4; ++c4) {
+                                    const float as[4] = {av[ph][2 * c4].x, av[ph][2 * c4].z, av[ph][2 * c4 + 1].x, av[ph][2 * c4 + 1].z};
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                        for (int t = 0; t < T; ++t)
+                                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[q], bs[t][4 * c4 + q], acc[t], 0, 0, 0);
                                 }
                             }
                         }
                     }
-                }
+                };
+                if (two) run(std::integral_constant<int, 2>{});
+                else run(std::integral_constant<int, 1>{});
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int n = (wv + 4 * t) * 32 + l32;
