@@ -10,6 +10,7 @@
 // generator chains and the patch critic; the 32 -> 32 layers' weight gradient is a per-unit GEMM on the matrix pipe
 // (convk_wgrad_mfma_kernel).  Numbers: profiles/r02_n1_kernelgan_trainer_timing.log.
 #include <algorithm>
+#include <type_traits>
 
 #include "kmsr_common.h"
 
@@ -383,19 +384,35 @@ __global__ void __launch_bounds__(512) convk_wgrad_mfma_kernel(const float* __re
             }
         }
         __syncthreads();
-        if (nq > 0) {
+        // all operand requests of a pixel row (8 steps: 8 A + 8 NQ B values) go out before its first MFMA -- written step by step hipcc
+        // waits for each ds_read_b32 right before its MFMA (seen in the .s) and the LDS latency is paid per step
+        auto run = [&](auto NQT) {
+            constexpr int NQ = decltype(NQT)::value;
             for (int row = 0; row < RT; ++row) {
                 const float* ar = arow + row * RT;
                 const int xo = row * IT;
+                float av[RT / 2], bv[NQ][RT / 2];
 #pragma unroll
                 for (int t8 = 0; t8 < RT / 2; ++t8) {
-                    const float a = ar[2 * t8];
+                    av[t8] = ar[2 * t8];
 #pragma unroll
-                    for (int q = 0; q < WM_MAXQ; ++q)
-                        if (q < nq) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xt[colbase[q] + xo + 2 * t8], acc[q], 0, 0, 0);
+                    for (int q = 0; q < NQ; ++q) bv[q][t8] = xt[colbase[q] + xo + 2 * t8];
                 }
+                asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]));
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    asm volatile("" : "+v"(bv[q][0]), "+v"(bv[q][1]), "+v"(bv[q][2]), "+v"(bv[q][3]), "+v"(bv[q][4]), "+v"(bv[q][5]), "+v"(bv[q][6]),
+                                 "+v"(bv[q][7]));
+#pragma unroll
+                for (int t8 = 0; t8 < RT / 2; ++t8)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t8], bv[q][t8], acc[q], 0, 0, 0);
             }
-        }
+        };
+        if (nq == 4) run(std::integral_constant<int, 4>{});
+        else if (nq == 3) run(std::integral_constant<int, 3>{});
+        else if (nq == 2) run(std::integral_constant<int, 2>{});
+        else if (nq == 1) run(std::integral_constant<int, 1>{});
     }
     float* pu = part + ((long long)u * NS + s) * (C * KK) * C;
 #pragma unroll
