@@ -162,24 +162,36 @@ __global__ void __launch_bounds__(256, S == 1 ? 2 : 1) conv3x3_mfma_kernel(const
     const int boff = half * (IH * IWP) + (2 * wv * S) * IWP + l32 * S;        // + (2*kp)*IH*IWP + (nt*S + dy)*IWP + dx
 
     // one chunk: 9 taps x 4 channel pairs x (2x2) MFMAs out of LDS buffer b
+    // The 4 operands of group (tap, kp) are requested one group AHEAD of their MFMAs (register pins keep hipcc from sinking the
+    // reads back: it otherwise emits  mfma x3, ds_read, s_waitcnt lgkmcnt(0), mfma  -- an LDS round trip per 4 MFMAs, which the
+    // one-workgroup-per-CU stride-2 instantiation cannot hide).
     auto mma_chunk = [&](int b, auto&& fetch, auto&& restage) {
         const float* inb = lds + b * BUF;
         const float* wb = inb + IN_FLOATS;
+        auto operands = [&](int tap, int kp, float& a0, float& a1, float& b0, float& b1) {
+            const int dy = tap / 3, dx = tap % 3;
+            a0 = wb[aoff + (tap * CK + 2 * kp) * COB];
+            a1 = wb[aoff + (tap * CK + 2 * kp) * COB + 32];
+            b0 = inb[boff + (2 * kp) * (IH * IWP) + dy * IWP + dx];
+            b1 = inb[boff + (2 * kp) * (IH * IWP) + (S + dy) * IWP + dx];
+        };
+        float a0, a1, b0, b1;
+        operands(0, 0, a0, a1, b0, b1);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
             if (tap == kFetchTap) fetch();
             if (tap == kRestageTap) restage();
 #pragma unroll
             for (int kp = 0; kp < CK / 2; ++kp) {
-                const float a0 = wb[aoff + (tap * CK + 2 * kp) * COB];
-                const float a1 = wb[aoff + (tap * CK + 2 * kp) * COB + 32];
-                const float b0 = inb[boff + (2 * kp) * (IH * IWP) + dy * IWP + dx];
-                const float b1 = inb[boff + (2 * kp) * (IH * IWP) + (S + dy) * IWP + dx];
+                float na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+                if (kp + 1 < CK / 2) operands(tap, kp + 1, na0, na1, nb0, nb1);
+                else if (tap + 1 < 9) operands(tap + 1, 0, na0, na1, nb0, nb1);
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
             }
         }
     };
