@@ -5,12 +5,12 @@
 //   B lane l holds B[k = 8*(l>>5) + j][px = l&31]         -> 16 bytes of the channels-last input tile [row][col][ci]
 //   D lane l holds px = l&31 and 16 output channels (reg&3) + 8*(reg>>2) + 4*(l>>5).
 //
-// Persistent workgroups (4 waves, one per CU): the layer's packed weights for one 64-channel output group
-// ([9][64][Cin] bf16, <= 74 KB, rows padded by 16 B against bank conflicts) are loaded into LDS ONCE, then the
-// workgroup streams its share of 8x32-pixel tiles: halo tile [10][34][Cin] bf16 -> LDS, 9 taps x Cin/16 MFMA steps,
-// epilogue (bias, ReLU, bf16 rounding) written to an LDS staging tile and stored as full channel rows (16 B per lane,
-// consecutive lanes consecutive addresses), residual added in fp32 on the way out.  PixelShuffle(2) is a permutation of
-// the staging tile: conv channel 4c+2i+j of pixel (y,x) lands in channel c of pixel (2y+i, 2x+j).
+// Persistent workgroups (4 waves, one per CU) stream 8x32-pixel tiles of one 64-channel output group: halo tile [10][34][Cin] bf16
+// in LDS (pixel rows padded by 16 B against bank conflicts), 9 taps x Cin/16 MFMA steps, epilogue (bias, ReLU, bf16 rounding)
+// written to an LDS staging tile and stored as full channel rows (16 B per lane, consecutive lanes consecutive addresses),
+// residual added in fp32 on the way out.  PixelShuffle(2) is a permutation of the staging tile: conv channel 4c+2i+j of pixel
+// (y,x) lands in channel c of pixel (2y+i, 2x+j).  Round 1's kernel kept the weight slab in LDS and ran the tile loop serially
+// (load, barrier, MFMA, barrier, epilogue, barrier, store); the kernel below replaced it (history: profiles/r01_config4_bf16_timing.log).
 #include "kmsr_common.h"
 
 #include <algorithm>
@@ -27,14 +27,6 @@ constexpr int BTH = 8, BTW = 32;          // output tile (rows x cols)
 constexpr int BIH = BTH + 2, BIW = BTW + 2;
 constexpr int BCO = 64;                   // output channels per workgroup pass
 constexpr int PADE = 8;                   // row padding in bf16 elements (16 bytes): conflict-free 16-B reads at 128-B strides
-
-// elements of the LDS region shared by the input halo tile and the output staging tile (largest of the three uses)
-__host__ __device__ constexpr int tile_region_elems(int Cin) {
-    const int a = BIH * BIW * (Cin + PADE);                  // input tile
-    const int b = BTH * BTW * (BCO + PADE);                  // staging, plain
-    const int c = (2 * BTH) * (2 * BTW) * (16 + PADE);       // staging, PixelShuffle
-    return a > b ? (a > c ? a : c) : (b > c ? b : c);
-}
 
 struct Bf16Params {
     int N, Cin, H, W, Cout;               // padded channel counts
@@ -95,188 +87,9 @@ __global__ void __launch_bounds__(256) nhwc_bf16_to_nchw_f32_kernel(const unsign
     }
 }
 
-template <bool PS, int KS>          // KS = padded Cin / 16
-__global__ void __launch_bounds__(256, 1) conv3x3_bf16_kernel(const unsigned short* __restrict__ xg,
-                                                              const unsigned short* __restrict__ wpk,
-                                                              const float* __restrict__ bias,
-                                                              const unsigned short* __restrict__ res,
-                                                              unsigned short* __restrict__ out, Bf16Params p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    constexpr int Cin = 16 * KS, CP = Cin + PADE;            // compile-time: LDS pitch of one pixel / one weight row (elements)
-    unsigned short* wl = smem;                               // [9][64][CP]
-    unsigned short* il = smem + 9 * BCO * CP;                // [10][34][CP]   (reused as the output staging tile)
-    float* sbias = reinterpret_cast<float*>(il + tile_region_elems(Cin));   // [64]
-    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int H = p.H, W = p.W;
-    constexpr int kvec = Cin / 8;                            // 16-byte vectors per pixel / weight row
-
-    // item = (cg, n, tile); a workgroup owns a contiguous range of items of ONE cg when possible (weights reloaded
-    // only when cg changes)
-    const int per = (p.n_items + (int)gridDim.x - 1) / (int)gridDim.x;
-    int item = blockIdx.x * per;
-    const int item_end = min(item + per, p.n_items);
-    int cur_cg = -1;
-    for (; item < item_end; ++item) {
-        const int per_cg = p.N * p.tiles;
-        const int cg = item / per_cg, rem = item % per_cg, n = rem / p.tiles, tile = rem % p.tiles;
-        const int ty0 = (tile / p.tiles_x) * BTH, tx0 = (tile % p.tiles_x) * BTW;
-        __syncthreads();                                     // previous item's staging reads are done
-        if (cg != cur_cg) {                                  // (re)load this output group's weights and bias
-            const u32x4* src = reinterpret_cast<const u32x4*>(wpk + (long long)cg * 9 * BCO * Cin);
-            for (int e = tid; e < 9 * BCO * kvec; e += 256) {
-                const int row = e / kvec, v = e % kvec;
-                *reinterpret_cast<u32x4*>(wl + row * CP + 8 * v) = src[e];
-            }
-            if (tid < BCO) sbias[tid] = (bias && cg * BCO + tid < p.Cout) ? bias[cg * BCO + tid] : 0.f;
-            cur_cg = cg;
-        }
-        // ---- input halo tile, channels-last: every pixel is Cin*2 contiguous bytes
-        const unsigned short* __restrict__ xn = xg + (long long)n * H * W * Cin;
-        {
-            // all loads are issued before any is consumed (a rolled load->store loop would pay one memory round trip
-            // per iteration): <= 11 x 16 bytes per thread for Cin = 64
-            constexpr int NLD = (BIH * BIW * 8 + 255) / 256;
-            const int n_in = BIH * BIW * kvec;
-            u32x4 vals[NLD];
-#pragma unroll
-            for (int t = 0; t < NLD; ++t) {
-                const int e = tid + 256 * t;
-                const int pix = e / kvec, v = e - pix * kvec, r = pix / BIW, c = pix - r * BIW;
-                const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
-                const bool ok = e < n_in && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                const u32x4 ld = *reinterpret_cast<const u32x4*>(xn + (ok ? ((long long)gy * W + gx) * Cin + 8 * v : 0));
-                vals[t] = ok ? ld : u32x4{0u, 0u, 0u, 0u};
-            }
-#pragma unroll
-            for (int t = 0; t < NLD; ++t) {
-                const int e = tid + 256 * t;
-                const int pix = e / kvec, v = e - pix * kvec;
-                if (e < n_in) *reinterpret_cast<u32x4*>(il + pix * CP + 8 * v) = vals[t];
-            }
-        }
-        __syncthreads();
-
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
-        const unsigned short* ap = wl + l32 * CP + 8 * half;                          // + (tap*64 + 32*mt)*CP + 16*ks
-        const unsigned short* bp = il + ((2 * wv) * BIW + l32) * CP + 8 * half;       // + ((nt+dy)*BIW + dx)*CP + 16*ks
-        // 9 x KS operand groups (A: 2 x 16 B of weights, B: 2 x 16 B of pixels, 4 MFMAs each).  One wave per SIMD: nothing
-        // else covers an LDS round trip, so group g+1 is requested before group g is multiplied; the asm pins keep the
-        // compiler from sinking the reads next to their MFMAs (it otherwise emits read,read,read,read,wait,4 x mfma).
-        constexpr int NG = 9 * KS;
-        auto fetch_group = [&](int g, bf16x8& a0, bf16x8& a1, bf16x8& b0, bf16x8& b1) {
-            const int tap = g / KS, ks = g % KS, dy = tap / 3, dx = tap % 3;
-            a0 = *reinterpret_cast<const bf16x8*>(ap + (tap * BCO) * CP + 16 * ks);
-            a1 = *reinterpret_cast<const bf16x8*>(ap + (tap * BCO + 32) * CP + 16 * ks);
-            b0 = *reinterpret_cast<const bf16x8*>(bp + (dy * BIW + dx) * CP + 16 * ks);
-            b1 = *reinterpret_cast<const bf16x8*>(bp + ((1 + dy) * BIW + dx) * CP + 16 * ks);
-        };
-        bf16x8 ca0, ca1, cb0, cb1;
-        fetch_group(0, ca0, ca1, cb0, cb1);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            bf16x8 na0 = ca0, na1 = ca1, nb0 = cb0, nb1 = cb1;
-            if (g + 1 < NG) fetch_group(g + 1, na0, na1, nb0, nb1);
-            asm volatile("" : "+v"(ca0), "+v"(ca1), "+v"(cb0), "+v"(cb1));
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca0, cb0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca0, cb1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca1, cb0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca1, cb1, acc[1][1], 0, 0, 0);
-            ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;
-        }
-        __syncthreads();                                     // all waves are done reading the input tile -> reuse it for staging
-
-        // ---- epilogue into the staging tile.  Non-PS: st[(row*32 + col)][64 co].  PS: st[((2row+i)*64 + 2col+j)][16 c]
-        constexpr int SP = PS ? 16 + PADE : BCO + PADE;      // staging pitch (elements)
-        unsigned short* st = il;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int row = 2 * wv + nt;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co0 = mt * 32 + 8 * g + 4 * half;                      // 4 consecutive channels <-> regs 4g..4g+3
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = acc[mt][nt][4 * g + r] + sbias[co0 + r];
-                        if (p.relu) v[r] = fmaxf(v[r], 0.f);
-                    }
-                    if constexpr (PS) {
-                        // conv channel co0 + r = 4c + 2i + j (co0 % 4 == 0): c = co0/4, (i,j) = (r>>1, r&1)
-                        const int c = co0 >> 2;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            st[((2 * row + (r >> 1)) * (2 * BTW) + 2 * l32 + (r & 1)) * SP + c] = f2bf(v[r]);
-                    } else {
-                        const unsigned lo = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                        const unsigned hi = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                        *reinterpret_cast<uint2*>(st + (row * BTW + l32) * SP + co0) = make_uint2(lo, hi);
-                    }
-                }
-            }
-        __syncthreads();
-        // ---- coalesced stores: 16-byte pieces, consecutive lanes consecutive addresses inside a pixel's channel row
-        if constexpr (PS) {
-            const int Cq = p.Cout >> 2;                       // channels of the shuffled output
-            const int H2 = 2 * H, W2 = 2 * W;
-            // staging holds [16 rows][64 cols][16 ch]; each pixel contributes 2 pieces of 8 channels at channel offset cg*16
-            for (int e = tid; e < (2 * BTH) * (2 * BTW) * 2; e += 256) {
-                const int piece = e & 1, pix = e >> 1, r = pix / (2 * BTW), c = pix % (2 * BTW);
-                const int oy = 2 * ty0 + r, ox = 2 * tx0 + c;
-                if (oy < H2 && ox < W2) {
-                    const u32x4 val = *reinterpret_cast<const u32x4*>(st + pix * SP + 8 * piece);
-                    *reinterpret_cast<u32x4*>(out + (((long long)n * H2 + oy) * W2 + ox) * Cq + cg * 16 + 8 * piece) = val;
-                }
-            }
-        } else {
-            const int pieces = min(BCO, p.Cout - cg * BCO) / 8;      // 16-byte pieces per pixel (2 for a 16-channel tail)
-            constexpr int NST = BTH * BTW * 8 / 256;                  // 8 pieces per thread
-            long long go[NST];
-            bool ok[NST];
-            u32x4 rv[NST];
-#pragma unroll
-            for (int t = 0; t < NST; ++t) {
-                const int e = tid + 256 * t;
-                const int piece = e & 7, pix = e >> 3, r = pix / BTW, c = pix % BTW;
-                const int oy = ty0 + r, ox = tx0 + c;
-                ok[t] = piece < pieces && oy < H && ox < W;
-                go[t] = ok[t] ? (((long long)n * H + oy) * W + ox) * p.Cout + cg * BCO + 8 * piece : 0;
-                rv[t] = u32x4{0u, 0u, 0u, 0u};
-            }
-            if (res) {                                                // block-uniform: all residual pieces in flight together
-#pragma unroll
-                for (int t = 0; t < NST; ++t) rv[t] = *reinterpret_cast<const u32x4*>(res + go[t]);
-            }
-#pragma unroll
-            for (int t = 0; t < NST; ++t) {
-                const int e = tid + 256 * t;
-                u32x4 val = *reinterpret_cast<const u32x4*>(st + (e >> 3) * SP + 8 * (e & 7));
-                if (res) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float a0 = bf2f((unsigned short)(val[q] & 0xffffu)) + bf2f((unsigned short)(rv[t][q] & 0xffffu));
-                        const float a1 = bf2f((unsigned short)(val[q] >> 16)) + bf2f((unsigned short)(rv[t][q] >> 16));
-                        val[q] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
-                    }
-                }
-                if (ok[t]) *reinterpret_cast<u32x4*>(out + go[t]) = val;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------------
-// Register-weight, double-buffered form of the kernel above (round 2; Cin <= 64).  The serial tile loop above pays two HBM round
-// trips per tile (input tile, residual) that nothing overlaps -- one workgroup of four waves per CU is all the 83 KB weight slab
-// leaves room for.  Here
+// Register-weight, double-buffered tile loop (Cin <= 64).  A serial tile loop pays two HBM round trips per tile (input tile,
+// residual) that nothing overlaps -- one workgroup of four waves per CU is all an 83 KB weight slab in LDS leaves room for.  Here
 //   * every wave keeps ITS A operands -- the whole 64 x 9 x Cin slab, 16 B per lane and (tap, k-step, co half): 288 VGPRs at
 //     Cin = 64 -- in registers (one wave per SIMD owns all 512 VGPRs anyway), which frees the LDS for two input buffers plus a
 //     separate staging tile and halves the LDS operand traffic of the MFMA phase;
@@ -554,11 +367,6 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0);
-}
-
-size_t bf16_lds_bytes(int Cin) {
-    const int CP = Cin + PADE;
-    return (size_t)(9 * BCO * CP + tile_region_elems(Cin)) * 2 + BCO * sizeof(float);
 }
 
 }  // namespace
