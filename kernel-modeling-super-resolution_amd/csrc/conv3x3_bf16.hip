@@ -100,11 +100,11 @@ __global__ void __launch_bounds__(256) nhwc_bf16_to_nchw_f32_kernel(const unsign
 // ------------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <int KS>
+template <int KS, int NW = 4>
 struct RwGeo {
     static constexpr int Cin = 16 * KS, CP = Cin + PADE, kvec = Cin / 8, UP = kvec + 1;     // 16-byte units per pixel incl. the pad unit
-    static constexpr int NPIX = BIH * BIW, NUNITS = NPIX * UP, NINSTR = (NUNITS + 63) / 64, NIW = (NINSTR + 3) / 4;
-    static constexpr int TILE_ELEMS = NIW * 4 * 64 * 8;                                     // bf16 elements of one input buffer
+    static constexpr int NPIX = BIH * BIW, NUNITS = NPIX * UP, NINSTR = (NUNITS + 63) / 64, NIW = (NINSTR + NW - 1) / NW;
+    static constexpr int TILE_ELEMS = NIW * NW * 64 * 8;                                     // bf16 elements of one input buffer
     static constexpr int ST_ELEMS = (2 * BTH) * (2 * BTW) * (16 + PADE) > BTH * BTW * (BCO + PADE) ? (2 * BTH) * (2 * BTW) * (16 + PADE)
                                                                                                   : BTH * BTW * (BCO + PADE);
     static constexpr size_t LDS_BYTES = (size_t)(2 * TILE_ELEMS + ST_ELEMS) * 2 + BCO * sizeof(float);
@@ -112,20 +112,27 @@ struct RwGeo {
 
 struct Origin { int n, ty0, tx0, cg; };      // image, tile origin and output-channel group of a work item
 
-// MT = 32-channel output blocks actually computed (1 for layers with <= 32 output channels, e.g. the 7-band tail: half the MFMAs)
-template <bool PS, int KS, bool RELU, int MT>
-__global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned short* __restrict__ xg,
+// MT = 32-channel output blocks actually computed (1 for layers with <= 32 output channels, e.g. the 7-band tail: half the MFMAs).
+// NW = waves per workgroup: 4 (wave w owns tile rows 2w, 2w+1 and all MT blocks) or 8 (MT = 2 only: waves w and w + 4 own the same
+// rows and ONE 32-channel block each -- half the weight slab per wave, so two waves fit a SIMD and cover each other's LDS / VALU
+// latencies in the epilogue and store phases; the matrix pipe sees the same MFMAs).
+template <bool PS, int KS, bool RELU, int MT, int NW>
+__global__ void __launch_bounds__(64 * NW, 1) conv3x3_bf16_rw_kernel(const unsigned short* __restrict__ xg,
                                                                  const unsigned short* __restrict__ wpk,
                                                                  const float* __restrict__ bias,
                                                                  const unsigned short* __restrict__ res,
                                                                  unsigned short* __restrict__ out, Bf16Params p) {
-    using G = RwGeo<KS>;
+    using G = RwGeo<KS, NW>;
+    constexpr int NT = 64 * NW;                            // threads
+    constexpr int MTW = NW == 8 ? 1 : MT;                  // 32-channel blocks per wave
+    static_assert(NW == 4 || (NW == 8 && MT == 2), "8 waves split the two channel blocks");
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];        // the ONLY LDS object: in0 | in1 | staging | bias
     constexpr int Cin = G::Cin, CP = G::CP, kvec = G::kvec, UP = G::UP;
     unsigned short* st = smem + 2 * G::TILE_ELEMS;
     float* sbias = reinterpret_cast<float*>(st + G::ST_ELEMS);
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rp = NW == 8 ? (wv & 3) : wv, mt0 = NW == 8 ? (wv >> 2) : 0;      // row pair and first channel block of this wave
     const int H = p.H, W = p.W;
     const int per_cg = p.N * p.tiles;
 
@@ -164,11 +171,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
     };
 
     // store / residual pieces of a thread: tile-invariant element offsets from the tile's first pixel (32-bit: a tile spans < 2^31)
-    constexpr int NST = BTH * BTW * 8 / 256;
+    constexpr int NST = BTH * BTW * 8 / NT;
     int go[NST], sr[NST], sc[NST];
 #pragma unroll
     for (int t = 0; t < NST; ++t) {
-        const int e = tid + 256 * t, pix = e >> 3;
+        const int e = tid + NT * t, pix = e >> 3;
         sr[t] = pix / BTW;
         sc[t] = pix % BTW;
         go[t] = (sr[t] * W + sc[t]) * p.Cout + 8 * (e & 7);
@@ -186,12 +193,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
     // residual piece t of the item at `o` -> rv[t] (a piece outside the image or past the channel tail reads the tile's first piece instead)
     u32x4 rv[NST];
     auto residual_piece = [&](const Origin& o, const unsigned short* __restrict__ rb, int pieces, int t) {
-        const bool okp = ((tid + 256 * t) & 7) < pieces && o.ty0 + sr[t] < H && o.tx0 + sc[t] < W;
+        const bool okp = ((tid + NT * t) & 7) < pieces && o.ty0 + sr[t] < H && o.tx0 + sc[t] < W;
         rv[t] = *reinterpret_cast<const u32x4*>(rb + (okp ? go[t] : 0));
     };
     auto residual_base = [&](const Origin& o) { return res + (((long long)o.n * H + o.ty0) * W + o.tx0) * p.Cout + o.cg * BCO; };
 
-    bf16x8 areg[9][KS][MT];
+    bf16x8 areg[9][KS][MTW];
     int cur_cg = -1, buf = 0;
     Origin cur = tile_origin(item), nxt_carry = cur;
     issue_tile(cur, 0);
@@ -213,8 +220,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        areg[tap][ks][mt] = *reinterpret_cast<const bf16x8*>(wsrc + (tap * BCO + 32 * mt) * Cin + 16 * ks);
+                    for (int mt = 0; mt < MTW; ++mt)
+                        areg[tap][ks][mt] = *reinterpret_cast<const bf16x8*>(wsrc + (tap * BCO + 32 * (mt0 + mt)) * Cin + 16 * ks);
         }
         // No vmcnt wait here: this item's tile was waited for before the previous item's stores went out (below), so those stores
         // -- which count on vmcnt too -- retire under this item's MFMA phase instead of stalling its start.
@@ -241,15 +248,15 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
 
         const long long tile_base = (((long long)n * H + ty0) * W + tx0) * p.Cout + cg * BCO;      // wave-uniform
 
-        f32x16 acc[MT][2];
+        f32x16 acc[MTW][2];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
         const unsigned short* il = smem + buf * G::TILE_ELEMS;
-        const unsigned short* bp = il + ((2 * wv) * BIW + l32) * CP + 8 * half;       // + ((nt+dy)*BIW + dx)*CP + 16*ks
+        const unsigned short* bp = il + ((2 * rp) * BIW + l32) * CP + 8 * half;       // + ((nt+dy)*BIW + dx)*CP + 16*ks
         constexpr int NG = 9 * KS;
         auto fetch_b = [&](int g, bf16x8& b0, bf16x8& b1) {
             const int tap = g / KS, ks = g % KS, dy = tap / 3, dx = tap % 3;
@@ -265,7 +272,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
             asm volatile("" : "+v"(cb0), "+v"(cb1));
             const int tap = g / KS, ks = g % KS;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < MTW; ++mt) {
                 acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[tap][ks][mt], cb0, acc[mt][0], 0, 0, 0);
                 acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[tap][ks][mt], cb1, acc[mt][1], 0, 0, 0);
             }
@@ -277,28 +284,28 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
         constexpr int SP = PS ? 16 + PADE : BCO + PADE;
         // the 32 bias values of this lane in ONE batch of LDS reads (cycle stamps, tools/diag/make_stamped_bf16.py: read -> wait ->
         // add per group of 4 channels exposed the LDS latency 16 times, 1900 cycles for 170 instructions)
-        f32x4 bv[MT][4];
+        f32x4 bv[MTW][4];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if constexpr (PS) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) bv[mt][g][r] = sbias[mt * 32 + 16 * half + 4 * r + g];
+                    for (int r = 0; r < 4; ++r) bv[mt][g][r] = sbias[(mt0 + mt) * 32 + 16 * half + 4 * r + g];
                 } else {
-                    bv[mt][g] = *reinterpret_cast<const f32x4*>(sbias + mt * 32 + 8 * g + 4 * half);
+                    bv[mt][g] = *reinterpret_cast<const f32x4*>(sbias + (mt0 + mt) * 32 + 8 * g + 4 * half);
                 }
             }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(bv[mt][0]), "+v"(bv[mt][1]), "+v"(bv[mt][2]), "+v"(bv[mt][3]));
+        for (int mt = 0; mt < MTW; ++mt) asm volatile("" : "+v"(bv[mt][0]), "+v"(bv[mt][1]), "+v"(bv[mt][2]), "+v"(bv[mt][3]));
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const int row = 2 * wv + nt;
+                const int row = 2 * rp + nt;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int co0 = mt * 32 + 8 * g + 4 * half;
+                    const int co0 = (mt0 + mt) * 32 + 8 * g + 4 * half;
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -307,7 +314,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
                     }
                     if constexpr (PS) {
                         // shuffled channels c = 8 mt + 4 half + r of sub-pixel (i, j) = (g >> 1, g & 1)
-                        *reinterpret_cast<uint2*>(st + ((2 * row + (g >> 1)) * (2 * BTW) + 2 * l32 + (g & 1)) * SP + 8 * mt + 4 * half) =
+                        *reinterpret_cast<uint2*>(st + ((2 * row + (g >> 1)) * (2 * BTW) + 2 * l32 + (g & 1)) * SP + 8 * (mt0 + mt) + 4 * half) =
                             make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                     } else {
                         *reinterpret_cast<uint2*>(st + (row * BTW + l32) * SP + co0) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
@@ -322,18 +329,19 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
         if constexpr (PS) {
             const int Cq = p.Cout >> 2;
             const int H2 = 2 * H, W2 = 2 * W;
-            constexpr int NPS = (2 * BTH) * (2 * BTW) * 2 / 256;    // 8 pieces per thread: all staging reads first, then the stores
+            constexpr int NPS = (2 * BTH) * (2 * BTW) * 2 / NT;    // 8 pieces per thread: all staging reads first, then the stores
             u32x4 val[NPS];
 #pragma unroll
             for (int t = 0; t < NPS; ++t) {
-                const int e = tid + 256 * t;
+                const int e = tid + NT * t;
                 val[t] = *reinterpret_cast<const u32x4*>(st + (e >> 1) * SP + 8 * (e & 1));
             }
-            asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]));
+#pragma unroll
+            for (int t = 0; t < (int)(sizeof(val) / sizeof(val[0])); t += 4) asm volatile("" : "+v"(val[t]), "+v"(val[t + 1]), "+v"(val[t + 2]), "+v"(val[t + 3]));
             unsigned short* ob = out + (((long long)n * H2 + 2 * ty0) * W2 + 2 * tx0) * Cq + cg * 16;      // wave-uniform
 #pragma unroll
             for (int t = 0; t < NPS; ++t) {
-                const int e = tid + 256 * t;
+                const int e = tid + NT * t;
                 const int piece = e & 1, pix = e >> 1, r = pix / (2 * BTW), c = pix % (2 * BTW);
                 if (2 * ty0 + r < H2 && 2 * tx0 + c < W2) *reinterpret_cast<u32x4*>(ob + (r * W2 + c) * Cq + 8 * piece) = val[t];
             }
@@ -344,10 +352,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
             u32x4 val[NST];
 #pragma unroll
             for (int t = 0; t < NST; ++t) {
-                const int e = tid + 256 * t;
+                const int e = tid + NT * t;
                 val[t] = *reinterpret_cast<const u32x4*>(st + (e >> 3) * SP + 8 * (e & 7));
             }
-            asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]));
+#pragma unroll
+            for (int t = 0; t < (int)(sizeof(val) / sizeof(val[0])); t += 4) asm volatile("" : "+v"(val[t]), "+v"(val[t + 1]), "+v"(val[t + 2]), "+v"(val[t + 3]));
             if (res) {
 #pragma unroll
                 for (int t = 0; t < NST; ++t)
@@ -360,7 +369,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_bf16_rw_kernel(const unsigned 
             }
 #pragma unroll
             for (int t = 0; t < NST; ++t) {
-                const bool okt = ((tid + 256 * t) & 7) < pieces && ty0 + sr[t] < H && tx0 + sc[t] < W;
+                const bool okt = ((tid + NT * t) & 7) < pieces && ty0 + sr[t] < H && tx0 + sc[t] < W;
                 if (okt) *reinterpret_cast<u32x4*>(out + tile_base + go[t]) = val[t];
             }
         }
@@ -429,31 +438,35 @@ extern "C" int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x, 
     p.n_items = (int)items;
     const int grid = (int)std::min<long long>(items, 256);
     const int ks = d->Cin / 16;
-    const size_t shmem = ks == 1 ? RwGeo<1>::LDS_BYTES : ks == 2 ? RwGeo<2>::LDS_BYTES : ks == 3 ? RwGeo<3>::LDS_BYTES : RwGeo<4>::LDS_BYTES;
+    const bool w8 = d->Cout > 32;                   // two 32-channel blocks: 8 waves, one block per wave
+    const size_t shmem = ks == 1 ? (w8 ? RwGeo<1, 8>::LDS_BYTES : RwGeo<1, 4>::LDS_BYTES)
+                       : ks == 2 ? (w8 ? RwGeo<2, 8>::LDS_BYTES : RwGeo<2, 4>::LDS_BYTES)
+                       : ks == 3 ? (w8 ? RwGeo<3, 8>::LDS_BYTES : RwGeo<3, 4>::LDS_BYTES)
+                                 : (w8 ? RwGeo<4, 8>::LDS_BYTES : RwGeo<4, 4>::LDS_BYTES);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const auto* xs = static_cast<const unsigned short*>(x);
     const auto* ws = static_cast<const unsigned short*>(packed_w);
     const auto* rs = static_cast<const unsigned short*>(residual);
     auto* os = static_cast<unsigned short*>(out);
-    auto launch = [&](auto kern) -> int {
+    auto launch = [&](auto kern, int threads) -> int {
         KMSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        kern<<<grid, 256, shmem, stream>>>(xs, ws, bias, rs, os, p);
+        kern<<<grid, threads, shmem, stream>>>(xs, ws, bias, rs, os, p);
         return KMSR_OK;
     };
     int rc = KMSR_OK;
-#define KMSR_BF16_LAUNCH(PS_, RL_, MT_)                                                             \
+#define KMSR_BF16_LAUNCH(PS_, RL_, MT_, NW_)                                                        \
     switch (ks) {                                                                                   \
-        case 1: rc = launch(conv3x3_bf16_rw_kernel<PS_, 1, RL_, MT_>); break;                       \
-        case 2: rc = launch(conv3x3_bf16_rw_kernel<PS_, 2, RL_, MT_>); break;                       \
-        case 3: rc = launch(conv3x3_bf16_rw_kernel<PS_, 3, RL_, MT_>); break;                       \
-        default: rc = launch(conv3x3_bf16_rw_kernel<PS_, 4, RL_, MT_>); break;                      \
+        case 1: rc = launch(conv3x3_bf16_rw_kernel<PS_, 1, RL_, MT_, NW_>, 64 * NW_); break;        \
+        case 2: rc = launch(conv3x3_bf16_rw_kernel<PS_, 2, RL_, MT_, NW_>, 64 * NW_); break;        \
+        case 3: rc = launch(conv3x3_bf16_rw_kernel<PS_, 3, RL_, MT_, NW_>, 64 * NW_); break;        \
+        default: rc = launch(conv3x3_bf16_rw_kernel<PS_, 4, RL_, MT_, NW_>, 64 * NW_); break;       \
     }
     if (d->pixel_shuffle) {
-        if (d->relu) { KMSR_BF16_LAUNCH(true, true, 2) } else { KMSR_BF16_LAUNCH(true, false, 2) }
+        if (d->relu) { KMSR_BF16_LAUNCH(true, true, 2, 8) } else { KMSR_BF16_LAUNCH(true, false, 2, 8) }
     } else if (d->Cout <= 32) {                     // one 32-channel block is enough (the 7-band tail: Cout_p = 16)
-        if (d->relu) { KMSR_BF16_LAUNCH(false, true, 1) } else { KMSR_BF16_LAUNCH(false, false, 1) }
+        if (d->relu) { KMSR_BF16_LAUNCH(false, true, 1, 4) } else { KMSR_BF16_LAUNCH(false, false, 1, 4) }
     } else {
-        if (d->relu) { KMSR_BF16_LAUNCH(false, true, 2) } else { KMSR_BF16_LAUNCH(false, false, 2) }
+        if (d->relu) { KMSR_BF16_LAUNCH(false, true, 2, 8) } else { KMSR_BF16_LAUNCH(false, false, 2, 8) }
     }
 #undef KMSR_BF16_LAUNCH
     if (rc != KMSR_OK) return rc;
