@@ -14,12 +14,12 @@ rep("struct Origin { int n, ty0, tx0, cg; };", "__device__ unsigned long long g_
 rep("    Origin cur = tile_origin(item), nxt_carry = cur;", "    const int item0 = item;\n    Origin cur = tile_origin(item), nxt_carry = cur;")
 rep("        __builtin_amdgcn_s_barrier();\n        asm volatile(\"\" ::: \"memory\");\n        if (more) issue_tile(nxt, buf ^ 1);",
     "        " + STAMP(0) + "        __builtin_amdgcn_s_barrier();\n        asm volatile(\"\" ::: \"memory\");\n        " + STAMP(1) + "        if (more) issue_tile(nxt, buf ^ 1);\n        " + STAMP(2))
-a = s.index("template <bool PS, int KS, bool RELU>")
+a = s.index("template <bool PS, int KS, bool RELU, int MT, int NW>")
 k = s[a:]
 k = k.replace("        // ---- epilogue into the staging tile (its own LDS region", "        " + STAMP(3) + "        // ---- epilogue into the staging tile (its own LDS region", 1)
 k = k.replace("        __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): staging complete\n        __builtin_amdgcn_s_barrier();\n        asm volatile(\"\" ::: \"memory\");\n        __builtin_amdgcn_s_waitcnt(0x0070);",
               "        __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): staging complete\n        " + STAMP(4) + "        __builtin_amdgcn_s_barrier();\n        asm volatile(\"\" ::: \"memory\");\n        " + STAMP(5) + "        __builtin_amdgcn_s_waitcnt(0x0070);\n        " + STAMP(6), 1)
-pat = "                for (int t = 0; t < NST; ++t) residual_piece(nxt, nrb, npc, t);\n            }\n        }\n"
+pat = "                if (okt) *reinterpret_cast<u32x4*>(out + tile_base + go[t]) = val[t];\n            }\n        }\n"
 assert k.count(pat) == 1
 k = k.replace(pat, pat + "        " + STAMP(7), 1)
 s = s[:a] + k
