@@ -13,6 +13,8 @@ per-rank wall time.  Rank 0 prints ONE JSON line.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -95,6 +97,7 @@ class DegradeWorkload:
         g = torch.Generator().manual_seed(rank)
         self.kid = torch.randint(0, 10, (batch,), generator=g, dtype=torch.int32).to(device)
         self.lr = torch.empty(batch, C, H // 4, W // 4, device=device)
+        self.sample_base = rank * batch           # global sample index of this rank's first patch (noise is world-size invariant)
         self.ws = kmsr_amd.workspace_for(self.hr.shape, self.bank.shape, 4, "stride", device)
         self.step_no = 0
         self.taps_ready = False
@@ -105,6 +108,7 @@ class DegradeWorkload:
     def step(self):
         kmsr_amd.degrade_batch(self.hr, self.bank, 4, down="stride", pad="zero", normalize=False,
                                kernel_idx=self.kid, sigma=self.sigma, noise="gaussian", seed=42, offset=self.step_no,
+                               sample_base=self.sample_base,
                                out=self.lr, workspace=self.ws, taps_ready=self.taps_ready, flags=L.FLAG_FORCE_FAST)
         self.taps_ready = True      # the bank is fixed: the tap table is built once (first warm-up step)
         self.step_no += 1
@@ -160,6 +164,7 @@ class DegradeSRWorkload:
         g = torch.Generator().manual_seed(rank)
         self.kid = torch.randint(0, 10, (batch,), generator=g, dtype=torch.int32).to(device)
         self.lr = torch.empty(batch, C, h, w, device=device)
+        self.sample_base = rank * batch           # global sample index of this rank's first patch (noise is world-size invariant)
         self.ws = kmsr_amd.workspace_for(self.hr.shape, self.bank.shape, 4, "stride", device)
         torch.manual_seed(0)
         self.net = SRNet(C, 64, 16, 4).to(device).eval()
@@ -207,6 +212,7 @@ class DegradeSRWorkload:
             e0.record()
         kmsr_amd.degrade_batch(self.hr, self.bank, 4, down="stride", pad="zero", normalize=False,
                                kernel_idx=self.kid, sigma=self.sigma, noise="gaussian", seed=42, offset=self.step_no,
+                               sample_base=self.sample_base,
                                out=self.lr, workspace=self.ws, taps_ready=self.taps_ready, flags=L.FLAG_FORCE_FAST)
         if self._record:
             e1.record()
@@ -418,7 +424,8 @@ class TrainWorkload:
         self.step_no, self.taps_ready = 0, False
         self.patches_per_step = batch
         self.fwd_flops_per_patch = self.net.flops_per_lr_pixel() * h * w
-        self.noise_seed = kd.rank_seed(42)       # every rank draws its own eps field (independent samples, like torch.randn_like per process)
+        self.noise_seed = 42
+        self.sample_base = kd.sample_base(batch)  # rank r holds global samples r*B .. r*B+B-1: independent eps per sample, world-size invariant
         # MFMA FLOPs the step ISSUES: forward, data gradient AND weight gradient of the F->F / F->4F layers run in the Winograd
         # F(2x2,3x3) domain (algorithmic / 2.25), as does the head's weight gradient; the head's forward and the tail's three legs
         # are direct.  The head has no data gradient (its input is data).
@@ -432,14 +439,15 @@ class TrainWorkload:
     def step(self):
         kid = torch.randint(0, 10, (self.B,), generator=self.gen, dtype=torch.int32)     # host tensor: range-checked without a device sync
         kmsr_amd.degrade_batch(self.hr, self.bank, 4, down="stride", pad="zero", normalize=False, kernel_idx=kid,
-                               sigma=self.sigma, noise="gaussian", seed=self.noise_seed, offset=self.step_no, out=self.lr,
+                               sigma=self.sigma, noise="gaussian", seed=self.noise_seed, offset=self.step_no,
+                               sample_base=self.sample_base, out=self.lr,
                                workspace=self.ws, taps_ready=self.taps_ready, flags=L.FLAG_FORCE_FAST)
         self.taps_ready = True
         self.step_no += 1
-        self.bucket.zero()
-        loss = torch.nn.functional.l1_loss(self.net(self.lr), self.hr)
+        self.bucket.zero()                   # arms the overlap hooks: the upper half of the gradient is all-reduced (async, RCCL's
+        loss = torch.nn.functional.l1_loss(self.net(self.lr), self.hr)     # own stream) while backward still runs the lower layers
         loss.backward()
-        self.bucket.all_reduce_mean()
+        self.bucket.finish()                 # launches the rest, waits, scales by 1/world
         self.opt.step()
         self.loss = loss
 
@@ -457,18 +465,76 @@ class TrainWorkload:
                 "step_ms": round(step_ms, 3)}
 
 
+class StubWorkload:
+    """CPU stand-in (tests only: `--workload stub` with KMSR_BENCH_BACKEND=gloo): a fixed 5 ms of host time per step and 16
+    'patches' per step, so tests/test_bench_launch.py can drive THIS file's launcher / rank / barrier / MAX-over-ranks / JSON
+    path at world size 2 without a GPU.  Never used on a GPU box and never reported as a measurement."""
+    name = "stub_sleep5ms_b16"
+
+    def __init__(self, device, rank, batch=16):
+        self.B, self.C, self.H, self.W = batch, 0, 0, 0
+        self.patches_per_step = batch
+        self.rank = rank
+
+    def step(self):
+        if os.environ.get("KMSR_BENCH_STUB_FAIL_RANK") == str(self.rank):
+            raise RuntimeError("stub workload: injected rank failure (tests/test_bench_launch.py)")
+        time.sleep(0.005)
+
+    def roofline(self, step_ms):
+        return None
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no process group in the environment: this parent -- which has made NO GPU call
+    (importing torch / kmsr_amd does not initialise HIP) -- starts N fresh rank processes with the same launcher the driver uses
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), relays rank 0's JSON line on
+    its own stdout (everything else the ranks print goes to stderr) and exits non-zero when any rank failed.  Nothing is
+    exec()ed: the ranks are ordinary child processes."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line_json = None
+    for line in proc.stdout:
+        if line.startswith("{") and '"metric"' in line:
+            line_json = line.rstrip("\n")
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc != 0:
+        sys.stderr.write(f"bench.py: a rank of the {n}-rank job failed (launcher exit code {rc})\n")
+        sys.exit(rc)
+    if line_json is None:
+        sys.stderr.write("bench.py: the ranks finished without printing the JSON line\n")
+        sys.exit(1)
+    print(line_json, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["degrade_sr", "degrade", "train", "sr_bf16"], default="degrade_sr")
+    ap.add_argument("--workload", choices=["degrade_sr", "degrade", "train", "sr_bf16", "stub"], default="degrade_sr")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs 3 / 4 / 5 lines (\"secondary\") after the headline")
     ap.add_argument("--layerwise-upsampler", action="store_true",
                     help="degrade_sr: time the headline with up1 / up2 / tail as three kernels.  Default: the collapsed upsampler (one "
                          "conv5x5 + PixelShuffle(4) + the 8 border-class operators on the outer LR ring -- an exact inference-time linear rewrite, pinned against the "
                          "layer-by-layer path at full size by tests/test_fullsize_gpu.py); the other form is reported under \"variants\".")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        launch_ranks(args.gpus, sys.argv[1:])          # before ANY GPU call in this process
+        return
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: the launcher's world size is used\n")
 
     from kmsr_amd import dist as kd
     # "nccl" is RCCL on ROCm; no group for a single process.  Rehearsal on a one-GPU box (several ranks sharing card 0,
@@ -477,31 +543,48 @@ def main():
     forced = os.environ.get("KMSR_BENCH_DEVICE")
     if forced is not None:
         os.environ["LOCAL_RANK_ORIG"] = os.environ.get("LOCAL_RANK", "0")
+    use_gpu = args.workload != "stub"
+    if use_gpu and backend == "nccl" and forced is None:
+        n_dev = torch.cuda.device_count()              # does not initialise HIP on this image
+        want = int(env_world or 1)
+        if n_dev < want:
+            sys.exit(f"bench.py: {want} ranks need {want} GPUs, {n_dev} visible (one rank per GPU over RCCL)")
     rank, world, local = kd.init_from_env(backend=backend)
-    dev_index = int(forced) if forced is not None else (local if world > 1 else 0)
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    L.require_gpu()
+    if use_gpu:
+        dev_index = int(forced) if forced is not None else (local if world > 1 else 0)
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
+        L.require_gpu()
+        sync = torch.cuda.synchronize
+    else:
+        device = torch.device("cpu")
 
-    wl = {"degrade_sr": DegradeSRWorkload, "degrade": DegradeWorkload, "train": TrainWorkload, "sr_bf16": SRBf16Workload}[args.workload](device, rank)
+        def sync():
+            pass
+
+    wl = {"degrade_sr": DegradeSRWorkload, "degrade": DegradeWorkload, "train": TrainWorkload, "sr_bf16": SRBf16Workload,
+          "stub": StubWorkload}[args.workload](device, rank)
     for _ in range(max(args.warmup, 1)):
         wl.step()
 
     def timed(steps):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
+        if use_gpu:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync()
         kd.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
-        ev0.record()                       # on torch's current stream == the stream the kernels are launched on
+        if use_gpu:
+            ev0.record()                   # on torch's current stream == the stream the kernels are launched on
         for _ in range(steps):
             wl.step()
-        ev1.record()
-        torch.cuda.synchronize()
+        if use_gpu:
+            ev1.record()
+        sync()
         kd.barrier()
-        torch.cuda.synchronize()
+        sync()
         el = kd.max_over_ranks(time.perf_counter() - t0, device=device)     # slowest rank defines the job's time
-        return el, ev0.elapsed_time(ev1) / steps
+        return el, (ev0.elapsed_time(ev1) / steps if use_gpu else el / steps * 1e3)
 
     fuse = args.workload == "degrade_sr" and not args.layerwise_upsampler
     if args.workload == "degrade_sr":
@@ -548,7 +631,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16" if args.workload == "sr_bf16" else "f32",
+            "dtype": "bf16" if args.workload == "sr_bf16" else ("none" if args.workload == "stub" else "f32"),
             "data": "synthetic",
             "config": {"workload": wl.name, "hr": [wl.B, wl.C, wl.H, wl.W], "factor": 4,
                        "sharding": f"independent patches, {wl.B}/GPU, no data-path collective"},

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KMSR_VERSION 100 /* 0.1.0 */
+#define KMSR_VERSION 101 /* 0.1.1: noise_sample_base / noise_sample_step, kmsr_gaussian_eps_f32 plane_base */
 
 #define KMSR_OK 0
 #define KMSR_E_BADARG (-1)      /* null pointer / bad enum / misaligned         -> Python ValueError   */
@@ -63,8 +63,12 @@ int kmsr_device_count(void);
  *   REPLICATE: pad() clamps to the image; ZERO: out-of-image taps contribute 0.
  *   normalize=1: K[r,c] /= sum(K[r,c]) when that sum is > 0 (C_30:93-97).
  *   row(n) = kernel_idx[n] if kernel_idx else (n_kernels == 1 ? 0 : n).
- *   GAUSSIAN: out += sigma[row(n),c] * eps(n*C+c, i, j) with the counter-based Philox stream
- *             documented in DESIGN.md ("noise stream"); (seed, offset) select the stream.
+ *   GAUSSIAN: out += sigma[row(n),c] * eps(g(n)*C+c, i, j) with the counter-based Philox stream
+ *             documented in DESIGN.md ("noise stream"); (seed, offset) select the stream and
+ *             g(n) = noise_sample_base + n * max(noise_sample_step, 1) is the GLOBAL index of local sample n,
+ *             so a rank that holds a shard of a larger batch (contiguous block: base = first global sample, step 1;
+ *             round-robin patch_ids[rank::world]: base = rank, step = world) draws exactly the noise a single
+ *             process draws for the same global samples (results invariant to the world size).
  *   POOL    : out += noise[noise_idx ? noise_idx[n] : n, c, i, j]   (noise is [pool_size,C,h,w])
  * ========================================================================================== */
 enum { KMSR_DOWN_AVGPOOL = 0, KMSR_DOWN_STRIDE = 1 };
@@ -93,6 +97,8 @@ typedef struct kmsr_degrade_desc {
     uint64_t seed;           /* KMSR_NOISE_GAUSSIAN                                                  */
     uint32_t offset;         /* KMSR_NOISE_GAUSSIAN: stream offset (e.g. training step)             */
     int32_t rows_per_chunk;  /* tuning: LR rows per wave in the row-streaming kernel, 0 = auto      */
+    uint32_t noise_sample_base; /* KMSR_NOISE_GAUSSIAN: global index of local sample 0 (0 for one process) */
+    uint32_t noise_sample_step; /* KMSR_NOISE_GAUSSIAN: global index step between local samples, 0 == 1     */
 } kmsr_degrade_desc;
 
 /* LR size for a descriptor (pure host arithmetic). */
@@ -124,9 +130,9 @@ size_t kmsr_degrade_bwd_workspace_bytes(const kmsr_degrade_desc* d);
 int kmsr_degrade_bwd_f32(const kmsr_degrade_desc* d, const float* hr, const float* grad_lr /* [N,C,h,w] */,
                          float* dkernels, float* dsigma, void* workspace, size_t workspace_bytes, void* stream);
 
-/* eps stream only: out[p,i,j] = eps(p,i,j)  (tests; p < planes) */
+/* eps stream only: out[p,i,j] = eps(plane_base + p, i, j)  (tests; p < planes) */
 int kmsr_gaussian_eps_f32(float* out, int32_t planes, int32_t h, int32_t w, uint64_t seed, uint32_t offset,
-                          void* stream);
+                          uint32_t plane_base, void* stream);
 
 /* ============================================================================================
  * Noise-pool construction.  D_build_noise_pool.py:41-53,88: out[t] = (geo - den)[:, top:top+cs, left:left+cs]

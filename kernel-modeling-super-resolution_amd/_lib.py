@@ -31,7 +31,7 @@ class DegradeDesc(C.Structure):
         ("factor", C.c_int32), ("down_mode", C.c_int32), ("pad_mode", C.c_int32),
         ("normalize", C.c_int32), ("noise_mode", C.c_int32), ("pool_size", C.c_int32),
         ("flags", C.c_uint32), ("seed", C.c_uint64), ("offset", C.c_uint32),
-        ("rows_per_chunk", C.c_int32),
+        ("rows_per_chunk", C.c_int32), ("noise_sample_base", C.c_uint32), ("noise_sample_step", C.c_uint32),
     ]
 
 
@@ -70,7 +70,7 @@ SYMBOLS = {
     "kmsr_degrade_f32": (C.c_int, [C.POINTER(DegradeDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kmsr_degrade_bwd_workspace_bytes": (_sz, [C.POINTER(DegradeDesc)]),
     "kmsr_degrade_bwd_f32": (C.c_int, [C.POINTER(DegradeDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "kmsr_gaussian_eps_f32": (C.c_int, [_vp, _i32, _i32, _i32, _u64, _u32, _vp]),
+    "kmsr_gaussian_eps_f32": (C.c_int, [_vp, _i32, _i32, _i32, _u64, _u32, _u32, _vp]),
     "kmsr_noise_crops_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "kmsr_conv3x3_packed_weight_floats": (_sz, [_i32, _i32]),
     "kmsr_conv3x3_pack_weights_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),

@@ -48,6 +48,7 @@ struct DegradeParams {
     float* lr;
     unsigned long long seed;
     unsigned offset;
+    unsigned nz_base, nz_step;  // noise plane of local (n, c) = nz_base + n * nz_step + c  (global sample index * C + c)
     int pad_zero;
     int noise_mode;
     int rows_per_chunk, n_chunks, n_strips, n_units, n_blocks;
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(256) degrade_generic_kernel(DegradeParams p) {
         }
         if (p.noise_mode == KMSR_NOISE_GAUSSIAN) {
             float z[4];
-            eps4(p.seed, p.offset, (unsigned)plane, (unsigned)(i >> 2), (unsigned)j, z);
+            eps4(p.seed, p.offset, p.nz_base + (unsigned)n * p.nz_step + (unsigned)c, (unsigned)(i >> 2), (unsigned)j, z);
             acc += p.sigma[krow * p.C + c] * pick4(z, i & 3);
         } else if (p.noise_mode == KMSR_NOISE_POOL) {
             const long long pi = p.nidx ? p.nidx[n] : n;
@@ -223,6 +224,7 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
     const int strip = t1 % p.n_strips;
     const int plane = t1 / p.n_strips;
     const int n = plane / p.C, c = plane - n * p.C;
+    const unsigned nz_plane = p.nz_base + (unsigned)n * p.nz_step + (unsigned)c;
     const int krow = p.kidx ? __builtin_amdgcn_readfirstlane(p.kidx[n]) : (p.n_kernels == 1 ? 0 : n);
     const float* __restrict__ taps = taps_all + (size_t)(krow * p.C + c) * (TY * TXP);
     const float* __restrict__ img = hr + n * p.sN + c * p.sC;
@@ -377,8 +379,7 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
                 if (p.noise_mode == KMSR_NOISE_GAUSSIAN && (il == 0 || (i & 3) == (up ? 3 : 0))) {
 #pragma unroll
                     for (int x = 0; x < NX; ++x)
-                        eps4(p.seed, p.offset, (unsigned)plane, (unsigned)(i >> 2), (unsigned)(xs0 + lane + kWave * x),
-                             z[x]);
+                        eps4(p.seed, p.offset, nz_plane, (unsigned)(i >> 2), (unsigned)(xs0 + lane + kWave * x), z[x]);
                 }
 #pragma unroll
                 for (int x = 0; x < NX; ++x) {
@@ -403,13 +404,14 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
     }
 }
 
-__global__ void gaussian_eps_kernel(float* out, int planes, int h, int w, unsigned long long seed, unsigned offset) {
+__global__ void gaussian_eps_kernel(float* out, int planes, int h, int w, unsigned long long seed, unsigned offset,
+                                    unsigned plane_base) {
     const long long total = (long long)planes * h * w;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(idx % w), i = (int)((idx / w) % h), pl = (int)(idx / ((long long)w * h));
         float z[4];
-        eps4(seed, offset, (unsigned)pl, (unsigned)(i >> 2), (unsigned)j, z);
+        eps4(seed, offset, plane_base + (unsigned)pl, (unsigned)(i >> 2), (unsigned)j, z);
         out[idx] = pick4(z, i & 3);
     }
 }
@@ -554,7 +556,10 @@ extern "C" int kmsr_degrade_f32(const kmsr_degrade_desc* d, const float* hr, con
     p.taps = static_cast<const float*>(workspace);
     p.n_kernels = d->n_kernels; p.kidx = kernel_idx; p.sigma = sigma; p.noise = noise;
     p.nidx = reinterpret_cast<const long long*>(noise_idx); p.lr = lr;
-    p.seed = d->seed; p.offset = d->offset; p.pad_zero = d->pad_mode == KMSR_PAD_ZERO; p.noise_mode = d->noise_mode;
+    p.seed = d->seed; p.offset = d->offset;
+    p.nz_step = (d->noise_sample_step ? d->noise_sample_step : 1u) * (unsigned)d->C;
+    p.nz_base = d->noise_sample_base * (unsigned)d->C;
+    p.pad_zero = d->pad_mode == KMSR_PAD_ZERO; p.noise_mode = d->noise_mode;
 
     // Row-chunk height.  It also fixes the summation direction per output row (odd chunks accumulate tap rows
     // bottom-up), so it is chosen identically for both kernels.
@@ -604,12 +609,12 @@ extern "C" int kmsr_degrade_f32(const kmsr_degrade_desc* d, const float* hr, con
 }
 
 extern "C" int kmsr_gaussian_eps_f32(float* out, int32_t planes, int32_t h, int32_t w, uint64_t seed, uint32_t offset,
-                                     void* stream) {
+                                     uint32_t plane_base, void* stream) {
     if (!out || planes < 0 || h < 0 || w < 0) return fail(KMSR_E_BADARG, "bad argument");
     const long long total = (long long)planes * h * w;
     if (!total) return KMSR_OK;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 32);
-    gaussian_eps_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(out, planes, h, w, seed, offset);
+    gaussian_eps_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(out, planes, h, w, seed, offset, plane_base);
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
 }

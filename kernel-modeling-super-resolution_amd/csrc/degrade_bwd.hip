@@ -34,6 +34,7 @@ struct BwdParams {
     int tiles_x, tiles, rows, cols, pitch, S;
     unsigned long long seed;
     unsigned offset;
+    unsigned nz_base, nz_step;  // noise plane of local (n, c) = nz_base + n * nz_step + c  (same addressing as the forward)
     int want_sigma;
 };
 
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(BTHREADS) degrade_bwd_kernel(BwdParams pr) {
         const int ib = tid / BT, jj = tid % BT;
         const int i = i0 + 4 * ib, j = j0 + jj;
         float z[4], sg = 0.f;
-        eps4(p.seed, p.offset, (unsigned)plane, (unsigned)(i >> 2), (unsigned)j, z);
+        eps4(p.seed, p.offset, p.nz_base + (unsigned)n * p.nz_step + (unsigned)c, (unsigned)(i >> 2), (unsigned)j, z);
 #pragma unroll
         for (int k = 0; k < 4; ++k) sg = fmaf(gs[(4 * ib + k) * BT + jj], z[k], sg);   // gs is 0 outside the image
         sred[tid] = sg;
@@ -265,7 +266,7 @@ __global__ void __launch_bounds__(BTHREADS) degrade_bwd_vb_kernel(BwdParams p) {
         const int l = tid - 448, ib = l / BT, jj = l % BT;
         const int i = i0 + 4 * ib, j = j0 + jj;
         float z[4], sg = 0.f;
-        eps4(p.seed, p.offset, (unsigned)plane, (unsigned)(i >> 2), (unsigned)j, z);
+        eps4(p.seed, p.offset, p.nz_base + (unsigned)n * p.nz_step + (unsigned)c, (unsigned)(i >> 2), (unsigned)j, z);
 #pragma unroll
         for (int k = 0; k < 4; ++k) sg = fmaf(gs[(4 * ib + k) * BT + jj], z[k], sg);   // gs is 0 outside the image
         sred[l] = sg;
@@ -421,7 +422,8 @@ __global__ void __launch_bounds__(BTHREADS) degrade_bwd_vb_strip_kernel(BwdParam
                 const int ib = lane / BT, jj = lane % BT;
                 const int i = cur.kb * BT + 4 * ib, j = cur.strip * BT + jj;
                 float z[4];
-                eps4(p.seed, p.offset, (unsigned)cur.plane, (unsigned)(i >> 2), (unsigned)j, z);
+                const unsigned sn = (unsigned)(cur.plane / p.C);
+                eps4(p.seed, p.offset, p.nz_base + sn * p.nz_step + ((unsigned)cur.plane - sn * (unsigned)p.C), (unsigned)(i >> 2), (unsigned)j, z);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) sg = fmaf(gb[(4 * ib + k) * BT + jj], z[k], sg);   // gradients are 0 outside the image
             }
@@ -553,6 +555,8 @@ extern "C" int kmsr_degrade_bwd_f32(const kmsr_degrade_desc* d, const float* hr,
     p.S = std::max(1, std::min(BT, BTHREADS / ntaps));
     if (ntaps > BTHREADS) return fail(KMSR_E_UNSUPPORTED, "degrade backward: kernels above 22x22 taps are not implemented");
     p.seed = d->seed; p.offset = d->offset;
+    p.nz_step = (d->noise_sample_step ? d->noise_sample_step : 1u) * (unsigned)d->C;
+    p.nz_base = d->noise_sample_base * (unsigned)d->C;
     p.want_sigma = dsigma != nullptr;
     const size_t lds = ((size_t)p.rows * p.pitch + BT * BT + (size_t)p.S * ntaps + 64) * sizeof(float);
     if (lds > 160 * 1024) return fail(KMSR_E_UNSUPPORTED, "degrade backward: tile does not fit LDS");

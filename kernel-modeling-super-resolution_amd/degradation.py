@@ -16,6 +16,7 @@ No CPU fallback exists: without libkmsr_hip.so or a GPU these functions raise.
 """
 import os
 import random
+import weakref
 
 import numpy as np
 import torch
@@ -47,32 +48,43 @@ def _as_dev_f32(t, dev):
     return t.to(device=dev, dtype=torch.float32)
 
 
-_CHECKED_IDX = {}     # (data_ptr, version, numel, bound) of device index tensors already range-checked
+_CHECKED_IDX = {}     # what -> (weakref to the tensor OBJECT, version, numel, bound) of the device index tensor last range-checked
 
 
 def _checked_index(idx, n, bound, what, device, dtype):
     """Index tensors are range-checked on the host (the reference's np.random.randint / einsum gather cannot leave
     [0, bound); an out-of-range index here would be an out-of-bounds DEVICE read of taps, sigma or the noise pool).
     CPU tensors are checked before the copy (no device sync); a device tensor costs one min/max read-back the first time
-    it is seen and nothing on later calls with the same unmodified tensor (the steady state of a training loop)."""
+    it is seen and nothing on later calls with the same unmodified tensor OBJECT (the steady state of a training loop).  The
+    cache entry is bound to the object by a weak reference: a fresh tensor that lands on a recycled allocator block (same
+    data_ptr, version 0) is a different object and is checked again."""
     if idx.numel() != n:
         raise AssertionError(f"{what} must hold one index per sample ({n}), got {idx.numel()}")
     if idx.device.type != "cuda":
         if n and (int(idx.min()) < 0 or int(idx.max()) >= bound):
             raise IndexError(f"{what} out of range [0, {bound}): min {int(idx.min())}, max {int(idx.max())}")
         return idx.to(device=device, dtype=dtype).contiguous()
-    key = (idx.data_ptr(), idx._version, n, bound)
-    if _CHECKED_IDX.get(what) != key:
+    ent = _CHECKED_IDX.get(what)
+    if ent is None or ent[0]() is not idx or ent[1:] != (idx._version, n, bound):
         if n:
             lo, hi = (int(v) for v in torch.aminmax(idx))
             if lo < 0 or hi >= bound:
+                _CHECKED_IDX.pop(what, None)
                 raise IndexError(f"{what} out of range [0, {bound}): min {lo}, max {hi}")
-        _CHECKED_IDX[what] = key
+        _CHECKED_IDX[what] = (weakref.ref(idx), idx._version, n, bound)
     return idx.to(device=device, dtype=dtype).contiguous()
 
 
+def _sample_addr(sample_base, sample_step, N, Cc):
+    """Validate the global-sample addressing of the noise stream: the plane counter (global sample * C + band) is 32 bits."""
+    base, step = int(sample_base), int(sample_step)
+    if base < 0 or step < 1 or (base + max(N - 1, 0) * step + 1) * Cc > 2 ** 32:
+        raise ValueError(f"noise stream addressing out of range: sample_base={base}, sample_step={step}, N={N}, C={Cc}")
+    return base, step
+
+
 def degrade_batch(hr, kernels, factor, *, down="avgpool", pad="replicate", normalize=True,
-                  kernel_idx=None, sigma=None, noise="none", seed=0, offset=0,
+                  kernel_idx=None, sigma=None, noise="none", seed=0, offset=0, sample_base=0, sample_step=1,
                   noise_pool=None, noise_idx=None, out=None, flags=0, rows_per_chunk=0, workspace=None,
                   taps_ready=False, validate_idx=True):
     """One fused blur + downsample + noise launch over a batch.
@@ -82,6 +94,10 @@ def degrade_batch(hr, kernels, factor, *, down="avgpool", pad="replicate", norma
     down     "avgpool" (C_30:120-122) | "stride" (train_gemini.py:134)
     pad      "replicate" (C_30:107-109) | "zero" (train_gemini.py:128)
     noise    "none" | "gaussian" (sigma [K,C], train_gemini.py:137-138) | "pool" (noise_pool [P,C,h,w], E:72-74)
+    seed / offset / sample_base / sample_step: the counter-based Gaussian stream is addressed by (seed, offset, GLOBAL sample
+             index, band, row, col); local sample n is global sample sample_base + n * sample_step.  A rank that holds a
+             shard of a larger batch passes its shard's position (dist.sample_base(N) for contiguous blocks; base=rank,
+             step=world for patch_ids[rank::world]) and draws exactly the noise one process draws for those samples.
     workspace / taps_ready: pass the same float32 CUDA tensor to successive calls that use the SAME kernels and
              geometry and set taps_ready=True from the second call on to skip rebuilding the tap table.
     validate_idx: range-check kernel_idx / noise_idx on the host (IndexError); pass False only for indices that are in
@@ -110,6 +126,7 @@ def degrade_batch(hr, kernels, factor, *, down="avgpool", pad="replicate", norma
     d.noise_mode = {"none": L.NOISE_NONE, "gaussian": L.NOISE_GAUSSIAN, "pool": L.NOISE_POOL}[noise]
     d.flags = int(flags)
     d.seed, d.offset = int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 32 - 1)
+    d.noise_sample_base, d.noise_sample_step = _sample_addr(sample_base, sample_step, N, Cc)
     d.rows_per_chunk = int(rows_per_chunk)
     h, w = L.C.c_int32(), L.C.c_int32()
     L.check(lib.kmsr_degrade_out_shape(d, h, w))
@@ -159,7 +176,8 @@ def degrade_batch(hr, kernels, factor, *, down="avgpool", pad="replicate", norma
 
 
 
-def degrade_backward(hr, grad_lr, ksize, factor, *, pad="zero", seed=0, offset=0, want_kernels=True, want_sigma=True):
+def degrade_backward(hr, grad_lr, ksize, factor, *, pad="zero", seed=0, offset=0, sample_base=0, sample_step=1,
+                     want_kernels=True, want_sigma=True):
     """Gradients of the V-B degradation (down="stride", normalize=False) w.r.t. per-sample kernels and sigmas
     (kmsr_degrade_bwd_f32; the chain the reference differentiates at train_gemini.py:117-138 / :219-222).
     hr [N,C,H,W], grad_lr [N,C,ceil(H/f),ceil(W/f)], ksize (kh, kw) -> (dkernels [N,C,kh,kw] | None, dsigma [N,C] | None)."""
@@ -179,6 +197,7 @@ def degrade_backward(hr, grad_lr, ksize, factor, *, pad="zero", seed=0, offset=0
     d.pad_mode = {"replicate": L.PAD_REPLICATE, "zero": L.PAD_ZERO}[pad]
     d.noise_mode = L.NOISE_GAUSSIAN if want_sigma else L.NOISE_NONE
     d.seed, d.offset = int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 32 - 1)
+    d.noise_sample_base, d.noise_sample_step = _sample_addr(sample_base, sample_step, N, Cc)
     h, w = -(-H // int(factor)), -(-W // int(factor))
     grad_lr = grad_lr.to(torch.float32).contiguous()
     assert grad_lr.is_cuda and tuple(grad_lr.shape) == (N, Cc, h, w), \
@@ -199,24 +218,25 @@ class DegradeFunction(torch.autograd.Function):
     chain rule); x is treated as data (no gradient)."""
 
     @staticmethod
-    def forward(ctx, x, kernels, sigma, factor, pad, seed, offset):
+    def forward(ctx, x, kernels, sigma, factor, pad, seed, offset, sample_base=0, sample_step=1):
         out = degrade_batch(x, kernels.detach(), factor, down="stride", pad=pad, normalize=False,
                             sigma=None if sigma is None else sigma.detach(),
-                            noise="none" if sigma is None else "gaussian", seed=seed, offset=offset)
+                            noise="none" if sigma is None else "gaussian", seed=seed, offset=offset,
+                            sample_base=sample_base, sample_step=sample_step)
         ctx.save_for_backward(x)
-        ctx.meta = (tuple(kernels.shape[2:]), factor, pad, seed, offset, sigma is not None)
+        ctx.meta = (tuple(kernels.shape[2:]), factor, pad, seed, offset, sigma is not None, sample_base, sample_step)
         return out
 
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        ksize, factor, pad, seed, offset, has_sigma = ctx.meta
+        ksize, factor, pad, seed, offset, has_sigma, sample_base, sample_step = ctx.meta
         want_k, want_s = ctx.needs_input_grad[1], has_sigma and ctx.needs_input_grad[2]
         dk = ds = None
         if want_k or want_s:
-            dk, ds = degrade_backward(x, g, ksize, factor, pad=pad, seed=seed, offset=offset, want_kernels=want_k,
-                                      want_sigma=want_s)
-        return None, dk, ds, None, None, None, None
+            dk, ds = degrade_backward(x, g, ksize, factor, pad=pad, seed=seed, offset=offset, sample_base=sample_base,
+                                      sample_step=sample_step, want_kernels=want_k, want_sigma=want_s)
+        return None, dk, ds, None, None, None, None, None, None
 
 
 def workspace_for(hr_shape, kernels_shape, factor, down="avgpool", device=None):

@@ -35,15 +35,16 @@ def shard_indices(n, rank, world):
     return list(range(rank, n, world))
 
 
-def rank_seed(base_seed, rank=None):
-    """Seed of THIS rank's counter-based noise stream.  The in-kernel Gaussian noise is addressed by (seed, offset, local
-    plane, row, col); with one seed for all ranks sample n of every rank would receive a bit-identical eps field each step,
-    unlike the reference's independent torch.randn_like draws (train_gemini.py:137).  Rank r therefore keys its stream with
-    base_seed + r * 0x9E3779B97F4A7C15 (mod 2^64, odd multiplier -> distinct keys for distinct ranks); rank 0 (and a
-    single process) keeps base_seed, so single-GPU results do not depend on whether a process group exists."""
+def sample_base(local_batch, rank=None):
+    """Global index of THIS rank's first sample when every rank holds a contiguous block of `local_batch` samples of the
+    step's global batch (rank r owns samples r*B .. r*B+B-1).  The in-kernel Gaussian noise is addressed by (seed, offset,
+    GLOBAL sample, band, row, col) (kmsr_degrade_desc.noise_sample_base / _step), so with this base the ranks draw independent
+    eps fields (the reference's torch.randn_like per sample, train_gemini.py:137) AND the concatenated result equals what one
+    process draws for the whole batch: results do not depend on the world size.  For the round-robin shard
+    patch_ids[rank::world] use sample_base=rank, sample_step=world instead."""
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
-    return (int(base_seed) + int(rank) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    return int(rank) * int(local_batch)
 
 
 def rank():
@@ -73,36 +74,98 @@ def sum_over_ranks(value, device="cpu"):
 
 
 class GradBucket:
-    """Flat fp32 gradient bucket for data-parallel training: grads are views into one contiguous buffer, so the
-    step's exchange is a single all-reduce (sum) followed by a scale by 1/world."""
+    """Flat fp32 gradient bucket for data-parallel training: grads are views into one contiguous buffer and the step's
+    exchange is an all-reduce (sum) of that buffer followed by a scale by 1/world.
 
-    def __init__(self, params):
+    Overlap with backward: the buffer is cut into `chunks` slices on parameter boundaries.  Backward produces gradients in
+    (roughly) reverse parameter order, so the LAST slice completes first; a post-accumulate hook counts a slice's parameters
+    and launches its asynchronous all-reduce the moment the slice is complete (RCCL runs it on its own stream behind the
+    kernels already queued), while backward goes on with the earlier layers.  finish() launches whatever is left (the first
+    slice; slices with unused parameters), waits and scales.  With a 6 MB gradient two slices are enough: each message stays
+    large enough to be bandwidth- rather than latency-bound on the point-to-point xGMI links."""
+
+    def __init__(self, params, chunks=2):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
+        off, offs = 0, []
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            offs.append(off)
             off += p.numel()
+        # slice boundaries: parameter boundaries closest to k*n/chunks
+        chunks = max(1, min(int(chunks), len(self.params) or 1))
+        cuts = [0]
+        for k in range(1, chunks):
+            tgt = n * k // chunks
+            b = min(range(len(offs)), key=lambda i: abs(offs[i] - tgt)) if offs else 0
+            if b > cuts[-1]:
+                cuts.append(b)
+        cuts.append(len(self.params))
+        self._slices = []                              # (first param, end param, flat start, flat end)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b > a:
+                self._slices.append((a, b, offs[a], offs[b] if b < len(offs) else n))
+        self._slice_of = {}
+        for k, (a, b, _, _) in enumerate(self._slices):
+            for p in self.params[a:b]:
+                self._slice_of[id(p)] = k
+        self._armed = False
+        self._pending, self._works = [], []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _distributed(self):
+        return dist.is_initialized() and dist.get_world_size() > 1
+
+    def _launch(self, k):
+        _, _, a, b = self._slices[k]
+        self._works[k] = dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True)
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        k = self._slice_of[id(p)]
+        self._pending[k] -= 1
+        if self._pending[k] == 0 and self._works[k] is None:
+            self._launch(k)
 
     def zero(self):
+        """Clear the gradients and arm the overlap hooks for the backward pass that follows."""
         self.flat.zero_()
+        self._pending = [b - a for a, b, _, _ in self._slices]
+        self._works = [None] * len(self._slices)
+        self._armed = self._distributed()
+
+    def launched(self):
+        """Slices whose all-reduce has already been launched (by the hooks, during backward)."""
+        return sum(w is not None for w in self._works)
 
     def all_reduce_mean(self, async_op=False):
-        """Average gradients over ranks.  async_op=True returns the work handle (overlap with the rest of backward);
-        call .finish(handle) before the optimizer step."""
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        """Average gradients over ranks.  async_op=True returns the work handles (call .finish(handles) before the optimizer
+        step); slices the hooks already launched during backward are not launched again."""
+        if not self._distributed():
             return None
-        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
-        if not async_op:
-            self.flat.div_(dist.get_world_size())
-        return work
+        self._armed = False
+        if len(self._works) != len(self._slices):
+            self._works = [None] * len(self._slices)
+        for k in range(len(self._slices)):
+            if self._works[k] is None:
+                self._launch(k)
+        works, self._works = self._works, [None] * len(self._slices)
+        if async_op:
+            return works
+        self.finish(works)
+        return None
 
-    def finish(self, work):
-        if work is not None:
-            work.wait()
-            self.flat.div_(dist.get_world_size())
+    def finish(self, work=None):
+        if not self._distributed():
+            return
+        if work is None:
+            work = self.all_reduce_mean(async_op=True)
+        for w in work:
+            w.wait()
+        self.flat.div_(dist.get_world_size())
 
 
 def broadcast_parameters(module, src=0):

@@ -97,8 +97,9 @@ class ContentAdaptiveDegradation(nn.Module):
         initial_kernels += torch.randn_like(initial_kernels) * 0.01
         self.kernel_bank = nn.Parameter(initial_kernels)                  # :62
         self.sigma_bank = nn.Parameter(torch.ones(n_kernels, n_channels) * 0.5)   # :66
-        self.noise_seed = 0       # (seed, offset) of the counter-based noise stream; offset advances per forward; the key
-        #                           actually used is dist.rank_seed(noise_seed): every data-parallel rank draws its own eps field
+        self.noise_seed = 0       # (seed, offset) of the counter-based noise stream; offset advances per forward.  Samples are
+        #                           addressed globally (dist.sample_base: rank r's batch is samples r*B .. r*B+B-1 of the step), so
+        #                           data-parallel ranks draw different eps fields and the fields do not depend on the world size
         self.noise_offset = 0
         self.downscale = 4        # train_gemini.py:134  out[:, :, ::4, ::4]
 
@@ -130,7 +131,7 @@ class ContentAdaptiveDegradation(nn.Module):
         batch_kernels = torch.einsum('bk, kchw -> bchw', weights, valid_kernels)    # :112
         batch_sigmas = torch.einsum('bk, kc -> bc', weights, valid_sigmas)          # :115
         out = DegradeFunction.apply(x.detach(), batch_kernels, batch_sigmas, self.downscale, "zero",
-                                    kd.rank_seed(self.noise_seed), self.noise_offset)
+                                    self.noise_seed, self.noise_offset, kd.sample_base(x.shape[0]), 1)
         self.noise_offset += 1
         return out, weights, valid_kernels
 
@@ -146,14 +147,14 @@ class ContentAdaptiveDegradation(nn.Module):
             # hard selection: einsum('bk,kchw->bchw') with one-hot weights IS a gather (:112-115)
             out = degrade_batch(x, valid_kernels, self.downscale, down="stride", pad="zero", normalize=False,
                                 kernel_idx=weights.argmax(dim=1).to(torch.int32), sigma=valid_sigmas, noise="gaussian",
-                                seed=kd.rank_seed(self.noise_seed), offset=self.noise_offset,
+                                seed=self.noise_seed, offset=self.noise_offset, sample_base=kd.sample_base(B),
                                 validate_idx=False)        # an argmax over the K logits is in [0, K) by construction
         else:
             batch_kernels = torch.einsum('bk, kchw -> bchw', weights, valid_kernels)   # :112
             batch_sigmas = torch.einsum('bk, kc -> bc', weights, valid_sigmas)        # :115
             out = degrade_batch(x, batch_kernels, self.downscale, down="stride", pad="zero", normalize=False,
-                                sigma=batch_sigmas, noise="gaussian", seed=kd.rank_seed(self.noise_seed),
-                                offset=self.noise_offset)
+                                sigma=batch_sigmas, noise="gaussian", seed=self.noise_seed,
+                                offset=self.noise_offset, sample_base=kd.sample_base(B))
         self.noise_offset += 1
         return out, weights, valid_kernels
 
@@ -179,11 +180,13 @@ class NoiseEstimator(nn.Module):
                 with torch.no_grad():     # identity blur of zeros + unit-sigma Gaussian epilogue = the eps field itself
                     eps = degrade_batch(torch.zeros_like(x), one, 1, down="stride", pad="zero", normalize=False,
                                         sigma=torch.ones((1, x.shape[1]), device=x.device), noise="gaussian",
-                                        seed=kd.rank_seed(self.noise_seed), offset=self.noise_offset)
+                                        seed=self.noise_seed, offset=self.noise_offset,
+                                        sample_base=kd.sample_base(x.shape[0]))
                 self.noise_offset += 1
             return x + eps * sigma.view(1, -1, 1, 1), sigma
         # identity blur (1x1 kernel, stride 1) + Gaussian epilogue of the fused kernel
         out = degrade_batch(x, one, 1, down="stride", pad="zero", normalize=False, sigma=sigma.view(1, -1),
-                            noise="gaussian", seed=kd.rank_seed(self.noise_seed), offset=self.noise_offset)
+                            noise="gaussian", seed=self.noise_seed, offset=self.noise_offset,
+                            sample_base=kd.sample_base(x.shape[0]))
         self.noise_offset += 1
         return out, sigma

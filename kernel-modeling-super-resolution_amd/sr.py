@@ -405,6 +405,7 @@ class _FusedUpsampler:
     pixel of that canvas sits in exactly one class), once per weight version; at run time ONE launch of kmsr_upsampler_frame_f32
     evaluates them for the 2W + 2(H-2) border LR pixels of every image and writes their 4x4 HR blocks over the interior launch's
     output.  Images smaller than MIN_SIZE LR pixels on a side run layer by layer (SRNet._forward_infer)."""
+    MAX_BANDS = 8    # kmsr_upsampler_frame_f32 keeps a band's 16 sub-pixel sums in registers for <= 8 bands (FMAXB); more bands run layer by layer
     MIN_SIZE = 8     # every border class must see an untruncated neighbourhood on its far side (>= 5 would do; 8 keeps tiles sane)
 
     def __init__(self):
@@ -550,7 +551,8 @@ class SRNet(nn.Module):
             t = self._conv(f"b{i}.1", blk.conv1, h, relu=True)
             h = self._conv(f"b{i}.2", blk.conv2, t, residual=h)
         h = self._conv("body_tail", self.body_tail, h, residual=f)
-        if self.fuse_upsampler and len(self.up) == 2 and min(h.shape[-2:]) >= _FusedUpsampler.MIN_SIZE:
+        if self.fuse_upsampler and len(self.up) == 2 and self.n_colors <= _FusedUpsampler.MAX_BANDS \
+                and min(h.shape[-2:]) >= _FusedUpsampler.MIN_SIZE:
             return self._fused_up(self, h)
         for i, up in enumerate(self.up):
             h = self._conv(f"up{i}", up, h, pixel_shuffle=True)      # conv F->4F with PixelShuffle(2) fused into the store

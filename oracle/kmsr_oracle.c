@@ -188,15 +188,16 @@ static inline float oracle_eps(uint64_t seed, uint32_t offset, uint32_t plane, u
     return (float)((i & 1) ? rad * sin(ang) : rad * cos(ang));
 }
 
-/* out[p,i,j] += sigma[p] * eps(p,i,j); sigma is [planes] */
+/* out[p,i,j] += sigma[p] * eps(plane_base + p,i,j); sigma is [planes].  plane_base = (global index of the first sample) * C:
+ * a shard of a larger batch draws the noise of its GLOBAL planes (results invariant to the world size). */
 int oracle_add_gaussian_noise(float* out, int planes, int h, int w, const float* sigma, uint64_t seed,
-                              uint32_t offset) {
+                              uint32_t offset, uint32_t plane_base) {
     if (!out || !sigma) return ORACLE_E_BADARG;
 #pragma omp parallel for collapse(2) schedule(static)
     for (int p = 0; p < planes; ++p)
         for (int i = 0; i < h; ++i)
             for (int j = 0; j < w; ++j)
-                out[((size_t)p * h + i) * w + j] += sigma[p] * oracle_eps(seed, offset, (uint32_t)p, (uint32_t)i, (uint32_t)j);
+                out[((size_t)p * h + i) * w + j] += sigma[p] * oracle_eps(seed, offset, plane_base + (uint32_t)p, (uint32_t)i, (uint32_t)j);
     return ORACLE_OK;
 }
 

@@ -117,11 +117,11 @@ def vb_backward(x, g, ksize=13, f=4, pad="zero"):
     return dk
 
 
-def vb_backward_sigma(g, seed, offset=0):
+def vb_backward_sigma(g, seed, offset=0, plane_base=0):
     """d/dsigma of add_gaussian_noise: sum_{i,j} g * eps with the same counter-based stream -> float64 [N,C]."""
     g = np.asarray(g, np.float64)
     N, C, h, w = g.shape
-    eps = gaussian_eps(N * C, h, w, seed, offset).reshape(N, C, h, w).astype(np.float64)
+    eps = gaussian_eps(N * C, h, w, seed, offset, plane_base).reshape(N, C, h, w).astype(np.float64)
     return (g * eps).sum(axis=(2, 3))
 
 
@@ -131,19 +131,20 @@ def philox_u32(seed, c0, c1, c2, c3):
     return np.array(list(out), np.uint32)
 
 
-def add_gaussian_noise(x, sigma, seed, offset=0):
-    """x [...,h,w] with prod(leading dims) planes; sigma one value per plane.  Returns x + sigma*eps."""
+def add_gaussian_noise(x, sigma, seed, offset=0, plane_base=0):
+    """x [...,h,w] with prod(leading dims) planes; sigma one value per plane.  Returns x + sigma*eps, eps addressed by the
+    GLOBAL plane index plane_base + p (plane_base = first global sample * C for a shard of a larger batch)."""
     x = _f32(x).copy()
     h, w = x.shape[-2:]
     planes = x.size // (h * w)
     sigma = _f32(np.broadcast_to(np.asarray(sigma, np.float32).reshape(-1), (planes,)))
-    _check(lib().oracle_add_gaussian_noise(_p(x), planes, h, w, _p(sigma), C.c_uint64(seed), C.c_uint32(offset)),
-           "add_gaussian_noise")
+    _check(lib().oracle_add_gaussian_noise(_p(x), planes, h, w, _p(sigma), C.c_uint64(seed), C.c_uint32(offset),
+                                            C.c_uint32(plane_base)), "add_gaussian_noise")
     return x
 
 
-def gaussian_eps(planes, h, w, seed, offset=0):
-    return add_gaussian_noise(np.zeros((planes, h, w), np.float32), np.ones(planes, np.float32), seed, offset)
+def gaussian_eps(planes, h, w, seed, offset=0, plane_base=0):
+    return add_gaussian_noise(np.zeros((planes, h, w), np.float32), np.ones(planes, np.float32), seed, offset, plane_base)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -28,13 +28,14 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in include/kmsr.h but not exported by libkmsr_hip.so"
         assert n in L.SYMBOLS, f"{n} has no ctypes prototype in _lib.SYMBOLS"
     assert sorted(L.SYMBOLS) == names, "ctypes table and header disagree"
-    assert lib.kmsr_version() == 100
+    assert lib.kmsr_version() == 101
 
 
 def test_struct_layout_matches_header():
-    # kmsr_degrade_desc: 4*i32, 3*i64, 9*i32 + u32, u64, u32, i32  (natural alignment)
-    assert C.sizeof(L.DegradeDesc) == 16 + 24 + 40 + 8 + 8
+    # kmsr_degrade_desc: 4*i32, 3*i64, 9*i32 + u32, u64, u32, i32, u32, u32  (natural alignment)
+    assert C.sizeof(L.DegradeDesc) == 16 + 24 + 40 + 8 + 8 + 8
     assert L.DegradeDesc.hr_stride_n.offset == 16 and L.DegradeDesc.seed.offset == 80
+    assert L.DegradeDesc.noise_sample_base.offset == 96 and L.DegradeDesc.noise_sample_step.offset == 100
 
 
 def _desc(**kw):

@@ -304,7 +304,10 @@ def test_conv5x5_ps4_vs_torch(N, Cin, H, W, Cout, bias, gpu_device):
 
 
 @pytest.mark.parametrize("colors,feats,blocks,shape", [(3, 64, 2, (2, 3, 40, 72)), (5, 32, 1, (1, 5, 18, 8)),
-                                                        (3, 64, 1, (1, 3, 64, 64)), (7, 32, 1, (2, 7, 9, 12))])
+                                                        (3, 64, 1, (1, 3, 64, 64)), (7, 32, 1, (2, 7, 9, 12)),
+                                                        # 9 bands: above the frame kernel's 8-band limit -> the default eval path
+                                                        # must run layer by layer instead of raising (round-2 advisor finding)
+                                                        (9, 32, 1, (1, 9, 12, 16))])
 def test_srnet_fused_upsampler_matches_layerwise(colors, feats, blocks, shape, gpu_device):
     """fuse_upsampler=True (one conv5x5+PS4 launch for the interior operator + one kmsr_upsampler_frame_f32 launch with the 8
     border-class operators) against the layer-by-layer path and the stock-torch oracle, borders included."""

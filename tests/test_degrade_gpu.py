@@ -114,6 +114,17 @@ def test_va_error_behaviour(gpu_device):
                                noise_idx=torch.tensor([1, 4]))
     ok = kmsr_amd.degrade_batch(hr5, bank, 4, down="stride", pad="zero", normalize=False, kernel_idx=torch.tensor([2, 0]).cuda())
     assert tuple(ok.shape) == (2, 5, 16, 16)
+    # the "already validated" cache is bound to the tensor OBJECT: a good device index tensor, freed, then a bad one of the same
+    # size that the caching allocator puts on the same block (same data_ptr, version 0) must still be range-checked
+    good = torch.tensor([1, 2], dtype=torch.int32).cuda()
+    kmsr_amd.degrade_batch(hr5, bank, 4, down="stride", pad="zero", normalize=False, kernel_idx=good)
+    addr = good.data_ptr()
+    del good
+    bad = torch.tensor([1, 5], dtype=torch.int32).cuda()
+    if bad.data_ptr() != addr:
+        print("note: allocator did not recycle the block; the check below still must fire")
+    with pytest.raises(IndexError):
+        kmsr_amd.degrade_batch(hr5, bank, 4, down="stride", pad="zero", normalize=False, kernel_idx=bad)
 
 
 @pytest.mark.parametrize("name,fast", [("b4_256", True), ("b3_250x253", False), ("b2_64", True)])
@@ -152,9 +163,48 @@ def test_gaussian_stream_matches_oracle(gpu_device):
     lib = L.load()
     for planes, h, w, seed, off in [(3, 37, 53, 1234, 0), (2, 64, 256, 2 ** 40 + 17, 9), (1, 5, 1, 0, 2 ** 31)]:
         out = torch.empty(planes, h, w).cuda()
-        L.check(lib.kmsr_gaussian_eps_f32(L.ptr(out), planes, h, w, seed, off, L.current_stream()))
+        L.check(lib.kmsr_gaussian_eps_f32(L.ptr(out), planes, h, w, seed, off, 0, L.current_stream()))
         want = oracle.gaussian_eps(planes, h, w, seed, off)
         assert_close(out.cpu().numpy(), want, rtol=0, atol=3e-6, what="eps")
+    # plane_base: planes [base, base + n) of the stream are exactly that slice of the stream from plane 0
+    full = torch.empty(7, 16, 24).cuda()
+    part = torch.empty(3, 16, 24).cuda()
+    L.check(lib.kmsr_gaussian_eps_f32(L.ptr(full), 7, 16, 24, 99, 5, 0, L.current_stream()))
+    L.check(lib.kmsr_gaussian_eps_f32(L.ptr(part), 3, 16, 24, 99, 5, 4, L.current_stream()))
+    assert torch.equal(full[4:], part)
+    assert_close(part.cpu().numpy(), oracle.gaussian_eps(3, 16, 24, 99, 5, plane_base=4), rtol=0, atol=3e-6, what="eps base")
+
+
+@pytest.mark.parametrize("flags", [0, L.FLAG_FORCE_GENERIC])
+def test_gaussian_noise_is_world_size_invariant(flags, gpu_device):
+    """the noise stream is keyed by (seed, offset, GLOBAL sample index), so a batch cut into shards -- two
+    contiguous blocks (bench.py / DDP: rank r owns samples r*B..), or the round-robin patch_ids[rank::world] of the per-file
+    loops (muti_kernel/train.py:150) -- gives, shard by shard, bit-exactly what one process computes for the whole batch."""
+    B, Cc, H, W = 6, 5, 128, 512
+    x = dev(landsat_like((B, Cc, H, W), 41))
+    kid = torch.tensor([2, 9, 4, 0, 7, 7], dtype=torch.int32)
+    kw = dict(down="stride", pad="zero", normalize=False, sigma=dev(K["moe_sigmas"]), noise="gaussian", seed=77, offset=3,
+              flags=flags)
+    whole = kmsr_amd.degrade_batch(x, dev(K["moe_kernels"]), 4, kernel_idx=kid, **kw)
+    # world 2, contiguous blocks
+    for r in range(2):
+        sl = slice(3 * r, 3 * r + 3)
+        part = kmsr_amd.degrade_batch(x[sl], dev(K["moe_kernels"]), 4, kernel_idx=kid[sl], sample_base=3 * r, **kw)
+        assert torch.equal(part, whole[sl]), f"contiguous shard {r}"
+    # world 3, round robin
+    for r in range(3):
+        part = kmsr_amd.degrade_batch(x[r::3].contiguous(), dev(K["moe_kernels"]), 4, kernel_idx=kid[r::3], sample_base=r,
+                                      sample_step=3, **kw)
+        assert torch.equal(part, whole[r::3]), f"round-robin shard {r}"
+    # ... and the oracle agrees on a shard addressed globally
+    clean = oracle.vb_blur_stride(x[3:].cpu().numpy(), K["moe_kernels"][kid[3:].numpy()], 4)
+    want = oracle.add_gaussian_noise(clean, K["moe_sigmas"][kid[3:].numpy()].reshape(-1), seed=77, offset=3, plane_base=3 * Cc)
+    assert_close(whole[3:].cpu().numpy(), want, rtol=RTOL, atol=5e-6, what="shard vs oracle")
+    # without the base the second shard would repeat the first shard's eps field (round-1 advisor finding)
+    p0 = kmsr_amd.degrade_batch(x[3:], dev(K["moe_kernels"]), 4, kernel_idx=kid[3:], **kw)
+    assert not torch.equal(p0, whole[3:])
+    with pytest.raises(ValueError):
+        kmsr_amd.degrade_batch(x[:1], dev(K["moe_kernels"]), 4, kernel_idx=kid[:1], sample_base=2 ** 32, **kw)
 
 
 @pytest.mark.parametrize("flags", [0, L.FLAG_FORCE_GENERIC])

@@ -55,17 +55,26 @@ def _worker(rank, world, port, q):
     torch.nn.functional.mse_loss(ref(x_all), y_all).backward()
     for a, b in zip(net.parameters(), ref.parameters()):
         assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-7)
-    # (4) per-rank noise streams: every rank keys the counter-based Gaussian stream differently (rank 0 keeps the base seed),
-    #     so sample n of two ranks never receives the same eps field (round-1 advisor finding)
+    # (3b) overlap: with hooks armed by zero(), the upper slice of the flat gradient is already in flight when backward returns
+    bucket.zero()
+    torch.nn.functional.mse_loss(net(x_all[sl]), y_all[sl]).backward()
+    assert len(bucket._slices) == 2 and bucket.launched() >= 1, (bucket._slices, bucket.launched())
+    bucket.finish()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-7)
+    # (4) world-size-invariant noise: the counter-based Gaussian stream is addressed by the GLOBAL sample index
+    #     (kd.sample_base = rank * local batch), so the ranks' fields differ AND their concatenation is bit for bit the field a
+    #     single process draws for the whole batch (round-2 advisor finding)
     import numpy as np
     import oracle
-    seeds = [None] * w
-    dist.all_gather_object(seeds, kd.rank_seed(42))
-    assert len(set(seeds)) == w and seeds[0] == 42 and kd.rank_seed(42, rank=0) == 42
-    eps = oracle.gaussian_eps(3, 8, 8, seed=kd.rank_seed(42), offset=7)
+    Bl, Cc = 3, 5
+    base = kd.sample_base(Bl)
+    assert base == rank * Bl and kd.sample_base(Bl, rank=0) == 0
+    eps = oracle.gaussian_eps(Bl * Cc, 8, 8, seed=42, offset=7, plane_base=base * Cc)
     fields = [None] * w
     dist.all_gather_object(fields, eps)
     assert not np.array_equal(fields[0], fields[1]) and abs(float(np.corrcoef(fields[0].ravel(), fields[1].ravel())[0, 1])) < 0.3
+    assert np.array_equal(np.concatenate(fields, axis=0), oracle.gaussian_eps(w * Bl * Cc, 8, 8, seed=42, offset=7))
     # grads are views of the flat buffer (a single collective per step)
     assert all(p_.grad.data_ptr() >= bucket.flat.data_ptr() for p_ in net.parameters())
     kd.barrier()

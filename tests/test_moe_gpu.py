@@ -141,6 +141,24 @@ def test_degrade_backward_vs_oracle(shape, k, f, pad, gpu_device):
     assert torch.equal(dk, dk2) and torch.equal(ds, ds2)
 
 
+@pytest.mark.parametrize("shape", [(4, 5, 40, 44), (4, 3, 72, 96)])     # tile kernel / strip-streaming kernel
+def test_degrade_backward_sigma_is_world_size_invariant(shape, gpu_device):
+    """dsigma regenerates the forward's eps: with the same global sample addressing a shard's dsigma is the matching slice of
+    the whole batch's (bit-exact), and equals the oracle's with the global plane base."""
+    from kmsr_amd.degradation import degrade_backward
+    N, C, H, W = shape
+    x = torch.from_numpy(landsat_like(shape, 43)).cuda()
+    g = torch.randn(N, C, -(-H // 4), -(-W // 4), generator=torch.Generator().manual_seed(44)).cuda()
+    _, ds = degrade_backward(x, g, 13, 4, seed=9, offset=3, want_kernels=False)
+    _, ds1 = degrade_backward(x[2:], g[2:], 13, 4, seed=9, offset=3, sample_base=2, want_kernels=False)
+    assert torch.equal(ds1, ds[2:])
+    _, ds2 = degrade_backward(x[1::2].contiguous(), g[1::2].contiguous(), 13, 4, seed=9, offset=3, sample_base=1, sample_step=2,
+                              want_kernels=False)
+    assert torch.equal(ds2, ds[1::2])
+    want = oracle.vb_backward_sigma(g[2:].cpu().numpy(), seed=9, offset=3, plane_base=2 * C)
+    assert_close(ds1.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * np.abs(want).max() + 1e-4, what="dsigma shard")
+
+
 def test_degrade_backward_errors(gpu_device):
     from kmsr_amd.degradation import degrade_backward
     x = torch.rand(1, 2, 16, 16, device=gpu_device)
