@@ -272,6 +272,20 @@ int kmsr_conv3x3_winov_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int
                                         void* stream);
 int kmsr_conv3x3_winov_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
                                const float* residual, float* out, void* stream);
+/* Winograd F(4x4,3x3) kernel (the SR net's F -> F body layers at inference; stride 1, bias / ReLU / residual epilogues, no
+ * PixelShuffle, no flags).  36 multiplies per 4x4 output block and (ci, co) pair instead of 64 for F(2x2,3x3) and 144 direct:
+ * 4x fewer MFMA FLOPs issued than the direct form.  Arithmetic stays fp32; the transforms with the points {0, +-1, +-2, inf}
+ * re-associate the sums: <= 2e-5 of the output scale vs float64 in the tests (measured 5e-6 .. 8e-6 for a 64 -> 64 layer).
+ * One persistent 4-wave workgroup per CU (one 512-register wave per SIMD) walks (image, cout group, 8x64-pixel tile) items as one
+ * stream of 4-channel steps; each lane computes the 6x6 input transform of its own patch and the output transform of its own
+ * 4x4 blocks; pre-transformed weights are loaded straight from L2 into the MFMA operand registers, raw rows arrive by buffer
+ * LDS-DMA (zero padding = out-of-range offsets).  Needs W % 4 == 0, 16-byte aligned x / packed_w / out / residual,
+ * Cin*H*W*4 < 2 GB per image.  Packed layout [ceil(Cout/64)][ceil(Cin/4)][2 halves][9 groups][2 blocks of 16][64 lanes][4]. */
+size_t kmsr_conv3x3_wino4_packed_weight_floats(int32_t Cin, int32_t Cout);
+int kmsr_conv3x3_wino4_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int32_t Cin, int32_t Cout, float* packed,
+                                        void* stream);
+int kmsr_conv3x3_wino4_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
+                               const float* residual, float* out, void* stream);
 /* Training-step variant: honours KMSR_CONV_FLAG_RELU_MASK and, when chan_sum != NULL (not with pixel_shuffle), also writes
  * per-channel partial sums of the tensor it stores: chan_sum[item][4][64] with item = (n * ceil(Cout/64) + cg) * tiles + tile
  * (kmsr_conv3x3_winov_chan_sum_floats(d) floats, every entry written, padding channels 0).  Summing over (n, tile, 4) gives

@@ -1,0 +1,477 @@
+// Winograd F(4x4,3x3) forward convolution on the fp32 matrix cores (semantics: include/kmsr.h, kmsr_conv3x3_wino4_fwd_f32).
+//
+// Why a second Winograd kernel.  conv3x3_wino_vreg.hip (F(2x2,3x3)) sits at 0.56-0.58 of the fp32 MFMA pipe and its remaining
+// overheads (transform VALU that cannot co-issue with the f32 MFMA, the LDS-DMA weight stream, the item hand-over) are structural
+// (DESIGN 4.4b).  F(4x4,3x3) needs 36 multiplies per 16 outputs and (ci, co) pair instead of 64: 1.78x fewer MFMAs for the same
+// convolution, and -- per output -- fewer transform instructions as well (144 + 100 VALU per 6x6 patch / 4x4 block instead of
+// 4 x (32 + 24)).  Arithmetic stays fp32 (v_mfma_f32_16x16x4_f32 is an exact fma chain); the transforms with the points
+// {0, +-1, +-2, inf} re-associate the sums: measured max error vs float64 5e-6 .. 8e-6 of the output scale for one 64 -> 64 layer
+// (F(2x2,3x3): 4e-7; tests hold 2e-5), 1.4e-6 through the 33-layer SR body (the skip connections carry the scale).
+//
+// Design (one persistent 4-wave workgroup per CU, ONE wave per SIMD with the whole 512-entry register file):
+//   * MFMA tile 16 channels x 16 tiles x 4 input channels.  A wave owns 32 output channels x 16 tiles (one tile row of 4x4 tiles =
+//     4 output rows x 64 columns) for ALL 36 transform points: 2 x 36 accumulator tiles x 4 registers = 288 registers
+//     (hipcc keeps them in the AGPR half).  Lane (tile t = lane & 15, channel kq = lane >> 4) supplies the B operand
+//     V[xi][4 s + kq][t] for every xi: exactly the 6x6 input transform B^T d B of ITS patch, which it computes itself (144 VALU per
+//     72 MFMAs) from the raw rows in LDS.  The output transform A^T M A is lane-local too: no exchange, no epilogue barrier.
+//   * the workgroup = 2 channel halves x 2 tile rows = 64 channels x (8 rows x 64 columns) per item, PERSISTENT over an interleaved
+//     item list; the 4-channel steps of all its items form ONE stream.
+//   * A operands (the pre-transformed weights U = G g G^T, 36 x 64 x 4 floats = 36 KB per step and workgroup) do NOT go through
+//     LDS: an LDS-DMA instruction costs ~60 cycles of the SIMD's MFMA time on gfx950 and a buffer_load + ds_write ~29
+//     (profiles/r02_ubench_dma_vs_reg.log); here every wave loads the 18 KB of ITS 32 channels per step with 18
+//     buffer_load_dwordx4 straight into the registers the MFMAs read (packed lane-linear: 1 KB per instruction), one whole step
+//     ahead (72 registers) -- the stream is the same 590 KB for every workgroup of a layer, i.e. L2 / L1 hits.
+//   * raw input rows (4 channels x 10 rows x 72 columns = 12 KB per step) arrive by LDS-DMA in a 3-slot ring, requested three
+//     steps ahead whatever item they belong to; padding (image border, channel tail, end of stream) is an out-of-range buffer
+//     offset, for which the hardware writes zeros: the transform has no masks and every wave issues the same 3 DMA instructions
+//     per step.  ONE barrier per step.
+//   * vmcnt retires in order: a step's 18 weight loads, 3 DMA instructions and an item's 32 stores (+ 32 skip-tensor loads) share
+//     one queue.  hipcc counts the register loads itself; the DMA is covered by an explicit counted wait before the barrier.
+// Requires W % 4 == 0 and 16-byte aligned x / packed_w / out / residual.
+#include "kmsr_common.h"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace kmsr {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+constexpr int QCK = 4;                  // input channels per step (one MFMA K)
+constexpr int QCO = 64;                 // output channels per workgroup
+constexpr int QTR = 2, QTC = 16;        // tiles per workgroup: 2 x 16 (output 8 rows x 64 columns)
+constexpr int QT = 256;                 // threads: 4 waves = (channel half hh) x (tile row tg)
+constexpr int QPTS = 36;
+constexpr int QUF = QPTS * QCK * QCO;   // 9216 floats = 36 KB of U per step: [hh 2][group 9][cbi 2][lane 64][jj 4]
+constexpr int QGROUPS = 9;              // groups of 4 transform points (8 MFMAs: 4 points x 2 channel blocks)
+constexpr int QRROWS = 4 * QTR + 2;     // 10 input rows
+constexpr int QRQ = (4 * QTC + 8) / 4;  // 18 float4 per row: columns x0-4 .. x0+67
+constexpr int QRCOLS = 4 * QRQ;         // 72
+constexpr int QPLANE_Q = 192;           // quads per channel plane in LDS (180 real + 12 pad: plane pitch 768 floats = 0 mod 64 banks ->
+                                        // the ds_read_b128 of a 16-lane tile row and of the 4 channels fall on disjoint banks)
+constexpr int QPLANE = 4 * QPLANE_Q;    // 768 floats
+constexpr int QRAWF = QCK * QPLANE;     // 3072 floats = 12 KB per ring slot = 12 wave-instructions of 1 KB
+constexpr int QRINSTR = QRAWF / 4 / QT; // 3 DMA instructions per wave and step
+constexpr int QNRAW = 3;                // ring slots: step s reads raw(s+1) and requests raw(s+3) into the slot raw(s) has left
+constexpr int QNA = 5;                  // register slots for A-operand groups: group g of a step lives in slot g % 5 and is requested 4 .. 9
+                                        // groups (>= 24 MFMAs) before its use
+constexpr int QVG = 2;                  // accumulator groups kept in ArchVGPRs (2 x 8 tiles x 4 = 64 registers); the other 7 x 32 = 224 in AGPRs
+constexpr int QMAX_BIAS = 1024;
+constexpr int QOFF_R = 0, QOFF_B = QNRAW * QRAWF, QLDS_FLOATS = QOFF_B + QMAX_BIAS;
+static_assert(QRINSTR * QT * 4 == QRAWF, "every wave issues the same number of DMA instructions");
+
+struct Wino4Params {
+    int N, Cin, H, W, Cout;
+    int tiles_x, tiles, cgs, nsteps, relu, n_items;
+};
+
+// packed[cg][step][hh][grp][cbi][lane][jj] = (G g G^T)[xi = 4 grp + jj]  for
+// (co, ci) = (cg*64 + hh*32 + cbi*16 + (lane & 15), step*4 + (lane >> 4)), zero padded; xi = 6 i + j.
+// G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]; computed in double, rounded once.
+__global__ void wino4_pack_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ packed, int nsteps,
+                                  long long total) {
+    const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int jj = (int)(idx & 3);
+        const int lane = (int)((idx >> 2) & 63);
+        const int cbi = (int)((idx >> 8) & 1);
+        long long r = idx >> 9;
+        const int grp = (int)(r % QGROUPS); r /= QGROUPS;
+        const int hh = (int)(r & 1); r >>= 1;
+        const int step = (int)(r % nsteps);
+        const int cg = (int)(r / nsteps);
+        const int xi = 4 * grp + jj, i = xi / 6, j = xi % 6;
+        const int cog = cg * QCO + hh * 32 + cbi * 16 + (lane & 15), cig = step * QCK + (lane >> 4);
+        double v = 0.0;
+        if (cog < Cout && cig < Cin) {
+            const float* g = w + ((long long)cog * Cin + cig) * 9;
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) v += G[i][a] * (double)g[a * 3 + b] * G[j][b];
+        }
+        packed[idx] = (float)v;
+    }
+}
+
+constexpr int q_wait_imm(int vm, int lgkm) { return (vm & 15) | ((vm >> 4) << 14) | (7 << 4) | ((lgkm & 15) << 8); }
+#define Q_FENCE() asm volatile("" ::: "memory")
+#define Q_SB() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ void q_barrier_lds() {   // LDS hand-over only (LDS-DMA in flight is covered by the caller's counted wait)
+    Q_FENCE();
+    __builtin_amdgcn_s_waitcnt(q_wait_imm(63, 0));
+    __builtin_amdgcn_s_barrier();
+    Q_FENCE();
+}
+template <int N>
+__device__ __forceinline__ void q_wait_vm() {       // all but the N newest vector-memory operations of this wave have completed
+    Q_FENCE();
+    __builtin_amdgcn_s_waitcnt(q_wait_imm(N, 15));
+    Q_FENCE();
+}
+
+// 1-D input transform B^T d (12 VALU):  B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]]
+__device__ __forceinline__ void bt6(float d0, float d1, float d2, float d3, float d4, float d5, float& o0, float& o1, float& o2,
+                                    float& o3, float& o4, float& o5) {
+    const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
+    const float c = d4 - d2, e = d3 - d1;
+    o0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+    o1 = a + b;
+    o2 = a - b;
+    o3 = fmaf(2.f, e, c);
+    o4 = fmaf(-2.f, e, c);
+    o5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+}
+// 1-D output transform A^T m (10 VALU):  A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]
+__device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1, float& y2,
+                                    float& y3) {
+    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+    y0 = m0 + s1 + s2;
+    y1 = fmaf(2.f, d2, d1);
+    y2 = fmaf(4.f, s2, s1);
+    y3 = fmaf(8.f, d2, d1) + m5;
+}
+
+template <bool HAS_RES>
+__global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __restrict__ xg, const float* __restrict__ wpk,
+                                                              const float* __restrict__ bias, const float* __restrict__ res,
+                                                              float* __restrict__ out, Wino4Params p) {
+    __shared__ __attribute__((aligned(16))) float lds[QLDS_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, t16 = lane & 15, kq = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = wv & 1, tg = wv >> 1;                    // channel half, tile row
+    const int H = p.H, W = p.W, S = p.nsteps;
+    const long long HW = (long long)H * W;
+
+    // items of this workgroup: vb, vb + nwg, ...  (vb = XCD-grouped id; see conv3x3_wino_vreg.hip: neighbouring tiles run at the
+    // same time on the CUs of one XCD, so halo rows are L2 hits)
+    const int nwg = gridDim.x, bq = nwg >> 3, br = nwg & 7, xcd = blockIdx.x & 7;
+    const int vb = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (blockIdx.x >> 3);
+    const int it0 = vb, istep = nwg;
+    if (it0 >= p.n_items) return;                           // block-uniform
+    const int n_my = (p.n_items - it0 + istep - 1) / istep;
+    const int T = n_my * S;                                 // steps in this workgroup's stream
+
+    // ---- A-operand stream: step gA of the stream = step cA of item itA (only its cout group matters).  a_cur / a_nxt = byte
+    //      offsets of the step being multiplied and of the one after it.
+    const auto urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpk), 0, 0xFFFFFFFFu, 0x00020000);
+    const unsigned a_lane = (unsigned)(hh * (QGROUPS * 2 * 256) + lane * 4) * 4u;   // byte offset of this lane inside a step of U
+    int gA = 0, cA = 0, itA = it0;
+    unsigned a_cur = (unsigned)(((it0 / p.tiles) % p.cgs) * S) * (unsigned)(QUF * 4), a_nxt = a_cur;
+    auto advance_a = [&]() {                                // a_cur <- a_nxt <- the step after it (past the end of the stream: stays)
+        a_cur = a_nxt;
+        ++gA;
+        if (gA < T) {
+            if (++cA == S) {
+                cA = 0;
+                itA += istep;
+                a_nxt = (unsigned)(((itA / p.tiles) % p.cgs) * S) * (unsigned)(QUF * 4);
+            } else {
+                a_nxt += (unsigned)(QUF * 4);
+            }
+        }
+    };
+    f32x4 A[QNA][2];
+    auto load_a = [&](unsigned step_off, int g) {           // group g of the step at step_off -> slot g % QNA
+#pragma unroll
+        for (int cbi = 0; cbi < 2; ++cbi)
+            A[g % QNA][cbi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, a_lane, step_off + (unsigned)((g * 2 + cbi) * 1024), 0));
+    };
+
+    // ---- raw rows: step gR = step cR of item itR.  Lane-linear quads: L = (3 wv + i) * 64 + lane <-> (channel = L / 192,
+    //      u = L % 192: row = u / 18, q = u % 18; u >= 180: plane padding).  BUFFER LDS-DMA on one descriptor per image whose
+    //      record count ends at the last real channel: out-of-image pieces and plane padding carry an out-of-range offset, channel
+    //      tails fall past the end of the records -- the hardware writes zeros for all of them (tools/ubench/buffer_lds_oob.hip), so
+    //      the transform needs no masks and no zero page.  (Not global_load_lds: hipcc models that FLAT-encoded instruction as
+    //      touching LDS *and* global memory and then drains vmcnt(0) / lgkmcnt(0) at the next counted dependency -- here the first
+    //      MFMA that reads a loaded weight register, i.e. a full HBM round trip per step.)
+    constexpr unsigned ROOB = 0x80000000u;
+    int gR = 0, cR = 0, itR = it0;
+    unsigned roff[QRINSTR];
+    const float* xnR = xg;
+    auto raw_map = [&]() {
+        const int tile = itR % p.tiles, n = itR / (p.tiles * p.cgs);
+        const int ty0 = (tile / p.tiles_x) * (4 * QTR), tx0 = (tile % p.tiles_x) * (4 * QTC);
+        xnR = xg + (long long)n * p.Cin * HW;
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+#pragma unroll
+        for (int i = 0; i < QRINSTR; ++i) {
+            const int L = (QRINSTR * wv + i) * 64 + lane_o;
+            const int ch = L / QPLANE_Q, u = L - ch * QPLANE_Q, row = u / QRQ, q = u - row * QRQ;
+            const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * q;
+            const bool ok = u < QRROWS * QRQ && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+            roff[i] = ok ? (unsigned)(ch * (int)HW + gy * W + gx) * 4u : ROOB;
+        }
+    };
+    raw_map();
+    auto issue_raw = [&]() {
+        // one descriptor per (image, step): base = the step's first channel, records = the channels that are left (raw-buffer range
+        // checks cover the VGPR offset only, not soffset -- so the channel position lives in the base).  Past the end of the stream:
+        // an empty descriptor (every lane out of range -> zeros; that slot is never multiplied).
+        const int ch_left = gR < T ? p.Cin - cR * QCK : 0;
+        const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xnR + (long long)cR * QCK * HW), 0,
+                                                          (unsigned)ch_left * (unsigned)HW * 4u, 0x00020000);
+        float* rb = lds + QOFF_R + (gR % QNRAW) * QRAWF;
+#pragma unroll
+        for (int i = 0; i < QRINSTR; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t*)(rb + (QRINSTR * wv + i) * 256), 16, roff[i], 0, 0, 0);
+        ++gR;
+        if (++cR == S) {
+            cR = 0;
+            itR += istep;
+            if (gR < T) raw_map();
+        }
+    };
+
+    // ---- patch of lane (tile t16, channel kq) in step g: raw rows 4 tg + r (r = 0..5), raw columns 4 t16 + 3 + j (j = 0..5):
+    //      one ds_read_b128 (columns 4 t16 + 4 .. + 7, j = 1..4) + one ds_read2_b32 (j = 0 and j = 5) per row.
+    const int pbase = kq * QPLANE + (4 * tg) * QRCOLS + 4 * t16 + 3;
+    struct Patch { f32x4 mid[6]; float lo[6], hi[6]; };
+    auto load_patch = [&](int g) {
+        const float* rp = lds + QOFF_R + (g % QNRAW) * QRAWF + pbase;
+        Patch P;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            P.mid[r] = *reinterpret_cast<const f32x4*>(rp + r * QRCOLS + 1);
+            P.lo[r] = rp[r * QRCOLS];
+            P.hi[r] = rp[r * QRCOLS + 5];
+        }
+        return P;
+    };
+    // V = B^T d B: column pass over the 6 patch columns (T[i][j] = sum_r B^T[i][r] d[r][j]), then row pass (V[i][:] = T[i][:] B)
+    auto cols_pass = [&](const Patch& P, float (&t)[6][6]) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float d[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) d[r] = j == 0 ? P.lo[r] : (j == 5 ? P.hi[r] : P.mid[r][j - 1]);
+            bt6(d[0], d[1], d[2], d[3], d[4], d[5], t[0][j], t[1][j], t[2][j], t[3][j], t[4][j], t[5][j]);
+            asm volatile("" : "+v"(t[0][j]), "+v"(t[1][j]), "+v"(t[2][j]), "+v"(t[3][j]), "+v"(t[4][j]), "+v"(t[5][j]));   // keep the VALU work where it is written (LLVM would sink it)
+        }
+    };
+    auto rows_pass = [&](const float (&t)[6][6], int i0, int i1, float (&v)[QPTS]) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+            bt6(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], v[6 * i + 0], v[6 * i + 1], v[6 * i + 2], v[6 * i + 3],
+                v[6 * i + 4], v[6 * i + 5]);
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+            asm volatile("" : "+v"(v[6 * i + 0]), "+v"(v[6 * i + 1]), "+v"(v[6 * i + 2]), "+v"(v[6 * i + 3]), "+v"(v[6 * i + 4]), "+v"(v[6 * i + 5]));
+    };
+
+    f32x4 acc[2][QPTS];    // [channel block of 16][xi]: rows = channels 4 kq + reg, column = tile t16
+
+    // bias vector -> LDS (plain stores BEFORE any DMA is in flight; published by the prologue's barrier)
+    for (int i = tid; i < QMAX_BIAS; i += QT) lds[QOFF_B + i] = (bias && i < p.Cout) ? bias[i] : 0.f;
+
+    // ---- prologue: raw(0..2), A(0); then V(0)
+    issue_raw();
+    issue_raw();
+    issue_raw();
+    advance_a();                                            // a_cur = step 0, a_nxt = step 1
+#pragma unroll
+    for (int g = 0; g < QNA; ++g) load_a(a_cur, g);
+    q_wait_vm<0>();
+    q_barrier_lds();
+    float vA[QPTS], vB[QPTS];
+    {
+        const Patch P = load_patch(0);
+        float t[6][6];
+        cols_pass(P, t);
+        rows_pass(t, 0, 6, vA);
+    }
+
+    // ---- one step: 72 MFMAs on V(cur) / A(cur), next step's A requested group by group into the registers just consumed, next
+    //      step's V computed in three VALU clusters (the f32 MFMA and the VALU do not co-issue on gfx950: cluster, do not interleave)
+    // The 288 accumulator registers exceed the 256 AGPRs: hipcc selects the AGPR form for every builtin MFMA of a kernel that needs
+    // AGPRs and would copy the surplus tiles in and out of a[0:3] around each use.  The QVG first groups (transform points 0 .. 4 QVG - 1)
+    // therefore accumulate in ArchVGPRs through the VGPR form of the instruction (inline asm); they are the first MFMAs of every step, so
+    // >= 56 other MFMAs lie between their last write and the epilogue's VALU reads (no MFMA-result hazard to pad by hand).
+#define Q_MFMA8(G, VC, FIRST)                                                                                             \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                    \
+        _Pragma("unroll") for (int cbi = 0; cbi < 2; ++cbi) {                                                             \
+            if constexpr ((G) < QVG) {                                                                                    \
+                if constexpr (FIRST)                                                                                      \
+                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc[cbi][4 * (G) + jj]) : "v"(A[(G) % QNA][cbi][jj]), "v"((VC)[4 * (G) + jj])); \
+                else                                                                                                      \
+                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[cbi][4 * (G) + jj]) : "v"(A[(G) % QNA][cbi][jj]), "v"((VC)[4 * (G) + jj])); \
+            } else {                                                                                                      \
+                acc[cbi][4 * (G) + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[(G) % QNA][cbi][jj], (VC)[4 * (G) + jj],    \
+                                                                              (FIRST) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[cbi][4 * (G) + jj], 0, 0, 0); \
+            }                                                                                                             \
+        }                                                                                                                 \
+    }
+    auto step = [&](int g, const float (&vc)[QPTS], float (&vn)[QPTS], auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        // raw(g+1) was requested at the top of step g-2; since then this wave has issued 18 + 3 + 18 vector-memory operations
+        // (+ an item's stores / skip loads, which only makes the count conservative)
+        q_wait_vm<2 * QGROUPS * 2 + QRINSTR>();
+        q_barrier_lds();                                     // raw(g+1) visible to every wave; raw(g)'s slot free
+        issue_raw();                                         // raw(g+3)
+        const Patch P = load_patch(g + 1);
+        float t[6][6];
+        Q_SB();
+        Q_MFMA8(0, vc, FIRST); Q_SB(); load_a(a_cur, 5); Q_SB();
+        Q_MFMA8(1, vc, FIRST); Q_SB(); load_a(a_cur, 6); Q_SB();
+        cols_pass(P, t);                                     // 72 VALU
+        Q_SB();
+        Q_MFMA8(2, vc, FIRST); Q_SB(); load_a(a_cur, 7); Q_SB();
+        Q_MFMA8(3, vc, FIRST); Q_SB(); load_a(a_cur, 8); Q_SB();
+        Q_MFMA8(4, vc, FIRST); Q_SB(); load_a(a_nxt, 4); Q_SB();
+        rows_pass(t, 0, 3, vn);                              // 36 VALU
+        Q_SB();
+        Q_MFMA8(5, vc, FIRST); Q_SB(); load_a(a_nxt, 0); Q_SB();
+        Q_MFMA8(6, vc, FIRST); Q_SB(); load_a(a_nxt, 1); Q_SB();
+        Q_MFMA8(7, vc, FIRST); Q_SB(); load_a(a_nxt, 2); Q_SB();
+        rows_pass(t, 3, 6, vn);                              // 36 VALU
+        Q_SB();
+        Q_MFMA8(8, vc, FIRST); Q_SB(); load_a(a_nxt, 3); Q_SB();
+        advance_a();
+    };
+
+    // ---- epilogue of one item: lane-local output transform, bias / ReLU / skip, 16-byte stores.  Buffer operations on one
+    //      descriptor per (image, 64-channel group): padding channels and out-of-image lanes are dropped by the range check.
+    const unsigned HWb = (unsigned)HW * 4u;
+    constexpr unsigned OOB = 0x80000000u;
+    auto epilogue = [&](int item) {
+        const int tile = item % p.tiles, rest = item / p.tiles;
+        const int n = rest / p.cgs, cg = rest % p.cgs;
+        const int y0 = (tile / p.tiles_x) * (4 * QTR) + 4 * tg, x0 = (tile % p.tiles_x) * (4 * QTC) + 4 * t16;
+        const unsigned nrec = (unsigned)min(QCO, p.Cout - cg * QCO) * HWb;
+        const auto ro = __builtin_amdgcn_make_buffer_rsrc(out + ((long long)n * p.Cout + cg * QCO) * HW, 0, nrec, 0x00020000);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res) + ((long long)n * p.Cout + cg * QCO) * HW, 0, nrec, 0x00020000);
+        unsigned vo[4];                                      // byte offset of (channel 0 of the group, row y0 + a, column x0)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) vo[a] = (x0 < W && y0 + a < H) ? (unsigned)((y0 + a) * W + x0) * 4u : OOB;
+        // sub-blocks k = cbi * 4 + r (one output channel of this lane each); skip-tensor rows are requested two sub-blocks ahead
+        f32x4 rr[3][4];
+        auto chan_off = [&](int k) { return (unsigned)((2 * hh + (k >> 2)) * 16 + 4 * kq + (k & 3)) * HWb; };
+        auto fetch = [&](int k) {
+            if constexpr (HAS_RES) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    rr[k % 3][a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[a] + chan_off(k), 0, 0));
+            }
+        };
+        fetch(0);
+        fetch(1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cbi = k >> 2, r = k & 3;
+            if (k + 2 < 8) fetch(k + 2);
+            const float bb = lds[QOFF_B + cg * QCO + (2 * hh + cbi) * 16 + 4 * kq + r];
+            float ma[4][6];                                  // A^T M  (rows of outputs x 6 transform columns)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                at6(acc[cbi][0 * 6 + j][r], acc[cbi][1 * 6 + j][r], acc[cbi][2 * 6 + j][r], acc[cbi][3 * 6 + j][r], acc[cbi][4 * 6 + j][r],
+                    acc[cbi][5 * 6 + j][r], ma[0][j], ma[1][j], ma[2][j], ma[3][j]);
+            f32x4 Y[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float y0_, y1_, y2_, y3_;
+                at6(ma[a][0], ma[a][1], ma[a][2], ma[a][3], ma[a][4], ma[a][5], y0_, y1_, y2_, y3_);
+                Y[a] = f32x4{y0_ + bb, y1_ + bb, y2_ + bb, y3_ + bb};
+                if (p.relu) Y[a] = f32x4{fmaxf(Y[a].x, 0.f), fmaxf(Y[a].y, 0.f), fmaxf(Y[a].z, 0.f), fmaxf(Y[a].w, 0.f)};
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if constexpr (HAS_RES) Y[a] += rr[k % 3][a];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[a]), ro, vo[a] + chan_off(k), 0, 0);
+            }
+        }
+    };
+
+    // ---- the stream
+    int item = it0;
+    for (int m = 0; m < n_my; ++m) {
+        int g = m * S;
+        step(g, vA, vB, std::true_type{});
+        ++g;
+        int s = 1;
+        for (; s + 1 < S; s += 2) {                         // pairs of steps (V ping-pong)
+            step(g, vB, vA, std::false_type{});
+            step(g + 1, vA, vB, std::false_type{});
+            g += 2;
+        }
+        if (s < S) {                                         // S even: one more step, V ends in vA
+            step(g, vB, vA, std::false_type{});
+        } else {                                             // S odd: the next item's V(0) sits in vB -> move it (block-uniform, rare)
+#pragma unroll
+            for (int i = 0; i < QPTS; ++i) vA[i] = vB[i];
+        }
+        epilogue(item);
+        item += istep;
+    }
+#undef Q_MFMA8
+}
+#undef Q_SB
+#undef Q_FENCE
+
+}  // namespace
+}  // namespace kmsr
+
+using namespace kmsr;
+
+extern "C" size_t kmsr_conv3x3_wino4_packed_weight_floats(int32_t Cin, int32_t Cout) {
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)ceil_div(Cout, QCO) * ceil_div(Cin, QCK) * QUF;
+}
+
+extern "C" int kmsr_conv3x3_wino4_pack_weights_f32(const float* w, int32_t Cin, int32_t Cout, float* packed, void* stream) {
+    if (!w || !packed || Cin <= 0 || Cout <= 0) return fail(KMSR_E_BADARG, "winograd-4x4 pack: bad argument");
+    const int nsteps = ceil_div(Cin, QCK);
+    const long long total = (long long)ceil_div(Cout, QCO) * nsteps * QUF;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    wino4_pack_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(w, Cin, Cout, packed, nsteps, total);
+    KMSR_HIP_CHECK(hipGetLastError());
+    return KMSR_OK;
+}
+
+extern "C" int kmsr_conv3x3_wino4_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
+                                          const float* residual, float* out, void* stream_) {
+    if (!d) return fail(KMSR_E_BADARG, "null descriptor");
+    if (d->flags) return fail(KMSR_E_BADARG, "winograd-4x4 conv takes no flags (0x%x)", d->flags);
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return fail(KMSR_E_BADARG, "bad conv shape");
+    if (d->stride != 1) return fail(KMSR_E_UNSUPPORTED, "winograd conv needs stride 1");
+    if (d->pixel_shuffle) return fail(KMSR_E_UNSUPPORTED, "winograd-4x4 conv has no PixelShuffle epilogue");
+    if (d->W % 4) return fail(KMSR_E_UNSUPPORTED, "winograd-4x4 conv needs W %% 4 == 0 (W=%d): rows move as aligned 16-byte pieces", d->W);
+    if (!x || !packed_w || !out) return fail(KMSR_E_BADARG, "null tensor pointer");
+    if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(packed_w) % 16 || reinterpret_cast<uintptr_t>(out) % 16 ||
+        reinterpret_cast<uintptr_t>(residual) % 16)
+        return fail(KMSR_E_BADARG, "winograd-4x4 conv needs 16-byte aligned input / weights / output / residual");
+    if (bias && d->Cout > QMAX_BIAS) return fail(KMSR_E_UNSUPPORTED, "winograd-4x4 conv stages the bias vector in LDS: Cout <= %d (Cout=%d)", QMAX_BIAS, d->Cout);
+    if ((long long)d->H * d->W * d->Cin * 4 >= (1ll << 31))   // 32-bit byte offsets inside one image of the input
+        return fail(KMSR_E_UNSUPPORTED, "winograd-4x4 conv: one input image (Cin*H*W*4 = %lld bytes) exceeds 2 GB", (long long)d->H * d->W * d->Cin * 4);
+    if ((long long)d->H * d->W * 4 * QCO >= (1ll << 31))      // 32-bit byte offsets inside one 64-channel output group
+        return fail(KMSR_E_UNSUPPORTED, "winograd-4x4 conv: H*W = %lld exceeds 2^23 pixels per plane", (long long)d->H * d->W);
+    Wino4Params p{};
+    p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
+    p.tiles_x = ceil_div(d->W, 4 * QTC);
+    p.tiles = p.tiles_x * ceil_div(d->H, 4 * QTR);
+    p.cgs = ceil_div(d->Cout, QCO);
+    p.nsteps = ceil_div(d->Cin, QCK);
+    p.relu = d->relu;
+    if ((long long)p.cgs * p.nsteps * QUF * 4 >= (1ll << 32)) return fail(KMSR_E_UNSUPPORTED, "packed weights exceed 4 GB");
+    const long long nitems = (long long)p.tiles * p.cgs * d->N;
+    if (nitems > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv grid too large");
+    p.n_items = (int)nitems;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int grid = (int)std::min<long long>(nitems, cus);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (residual)
+        conv3x3_wino4_kernel<true><<<grid, QT, 0, stream>>>(x, packed_w, bias, residual, out, p);
+    else
+        conv3x3_wino4_kernel<false><<<grid, QT, 0, stream>>>(x, packed_w, bias, residual, out, p);
+    KMSR_HIP_CHECK(hipGetLastError());
+    return KMSR_OK;
+}

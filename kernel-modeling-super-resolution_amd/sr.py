@@ -57,21 +57,37 @@ def pack_conv3x3_weight_wino_vreg(weight):
     return packed
 
 
+def pack_conv3x3_weight_wino4(weight):
+    """[Cout,Cin,3,3] -> G g G^T (6x6 points, F(4x4,3x3)) packed for conv3x3(..., algo="winograd4"): per 4-channel step the 36 KB a
+    workgroup multiplies, lane-linear per wave and group of 4 transform points (one buffer_load_dwordx4 per lane and group)."""
+    lib = L.load()
+    assert weight.is_cuda and weight.dtype == torch.float32 and weight.ndim == 4 and weight.shape[2:] == (3, 3)
+    w = weight.detach().contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    packed = torch.empty(lib.kmsr_conv3x3_wino4_packed_weight_floats(Cin, Cout), device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        L.check(lib.kmsr_conv3x3_wino4_pack_weights_f32(L.ptr(w), Cin, Cout, L.ptr(packed), L.current_stream()))
+    return packed
+
+
 def winograd_eligible(cin, cout, stride=1, width=2):
     """Where the Winograd kernel applies/pays: stride 1, even width (patch rows are fetched as aligned float2) and
     enough channels that the 64x16 chunk tiles are not mostly padding."""
     return stride == 1 and width % 2 == 0 and cin >= 16 and cout >= 32
 
 
-def pick_algo(cin, cout, stride, width, use_winograd=True, plain=False):
+def pick_algo(cin, cout, stride, width, use_winograd=True, plain=False, f4=False):
     """Kernel for a stride-1 3x3 conv of this shape: the persistent LDS-DMA Winograd kernel when rows are 16-byte aligned
     (W % 4 == 0) and the bias vector fits its LDS staging (Cout <= 1024), the register-staged Winograd kernel for other even
     widths, the direct MFMA / VALU kernels otherwise.  plain=True (no residual, no PixelShuffle) lets layers with <= 8 input
-    channels take the small-Cin kernel."""
+    channels take the small-Cin kernel.  f4=True (the caller has a bias / ReLU / residual epilogue only: no PixelShuffle, no
+    training extras) lets aligned layers take the Winograd F(4x4,3x3) kernel (4x fewer MFMA FLOPs than direct, 2.25x for F(2x2))."""
     if plain and stride == 1 and cin <= 8 and cout >= 32 and width % 4 == 0:
         return "smallci"
     if not (use_winograd and winograd_eligible(cin, cout, stride, width)):
         return "direct"
+    if f4 and width % 4 == 0 and cout <= 1024:
+        return "winograd4"
     return "winograd_vreg" if width % 4 == 0 and cout <= 1024 else "winograd"
 
 
@@ -79,7 +95,7 @@ def pack_for(algo, weight):
     if algo == "smallci":                       # the small-Cin kernel reads the [Cout,Cin,3,3] tensor itself
         return weight.detach().to(torch.float32).contiguous()
     return {"direct": pack_conv3x3_weight, "winograd": pack_conv3x3_weight_wino,
-            "winograd_vreg": pack_conv3x3_weight_wino_vreg}[algo](weight)
+            "winograd_vreg": pack_conv3x3_weight_wino_vreg, "winograd4": pack_conv3x3_weight_wino4}[algo](weight)
 
 
 def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuffle=False, stride=1, out=None,
@@ -93,7 +109,7 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     if not (x.is_cuda and x.dtype == torch.float32 and x.ndim == 4):
         raise ValueError("x must be a 4-D float32 CUDA tensor")
     x = x.contiguous()
-    if algo in ("winograd_vreg", "smallci") and x.data_ptr() % 16:
+    if algo in ("winograd_vreg", "winograd4", "smallci") and x.data_ptr() % 16:
         x = x.clone()                    # a view at an odd storage offset: these kernels fetch 16-byte pieces
     N, Cin, H, W = x.shape
     if algo == "smallci":
@@ -122,11 +138,14 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
         assert residual is None and not relu and not pixel_shuffle
         residual = relu_mask
         d.flags = L.CONV_FLAG_RELU_MASK
-    wino = algo in ("winograd", "winograd_vreg")
+    wino = algo in ("winograd", "winograd_vreg", "winograd4")
+    if algo == "winograd4" and pixel_shuffle:
+        raise NotImplementedError("the Winograd F(4x4,3x3) kernel has no PixelShuffle epilogue")
     if wino and stride != 1:
         raise NotImplementedError("winograd conv needs stride 1")
     need = {"direct": lib.kmsr_conv3x3_packed_weight_floats, "winograd": lib.kmsr_conv3x3_wino_packed_weight_floats,
-            "winograd_vreg": lib.kmsr_conv3x3_winov_packed_weight_floats}[algo](Cin, int(cout))
+            "winograd_vreg": lib.kmsr_conv3x3_winov_packed_weight_floats,
+            "winograd4": lib.kmsr_conv3x3_wino4_packed_weight_floats}[algo](Cin, int(cout))
     assert packed_w.is_cuda and packed_w.dtype == torch.float32 and packed_w.numel() == need, \
         f"packed weight has {packed_w.numel()} floats, conv {Cin}->{cout} needs {need}"
     oshape = (N, cout // 4, 2 * Ho, 2 * Wo) if pixel_shuffle else (N, cout, Ho, Wo)
@@ -140,6 +159,8 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     if residual is not None:
         residual = residual.contiguous()
         assert tuple(residual.shape) == oshape and residual.is_cuda
+        if algo == "winograd4" and residual.data_ptr() % 16:
+            residual = residual.clone()
     with torch.cuda.device(x.device):
         if chan_sum:
             part = torch.empty(lib.kmsr_conv3x3_winov_chan_sum_floats(d), device=x.device, dtype=torch.float32)
@@ -148,6 +169,7 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
             cgs = (cout + 63) // 64                  # part[n][cg][tile][4][64] -> per-channel totals
             return out, part.view(N, cgs, -1, 64).sum(dim=(0, 2)).reshape(-1)[:cout]
         fwd = {"direct": lib.kmsr_conv3x3_fwd_f32, "winograd": lib.kmsr_conv3x3_wino_fwd_f32,
+               "winograd4": lib.kmsr_conv3x3_wino4_fwd_f32,
                "winograd_vreg": lib.kmsr_conv3x3_winov_fwd_ex_f32 if d.flags else lib.kmsr_conv3x3_winov_fwd_f32}[algo]
         if algo == "winograd_vreg" and d.flags:
             L.check(fwd(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out), None, L.current_stream()))
@@ -504,7 +526,8 @@ class SRNet(nn.Module):
         self.up = nn.ModuleList([nn.Conv2d(n_feats, 4 * n_feats, 3, padding=1) for _ in range(int(math.log2(scale)))])
         self.tail = nn.Conv2d(n_feats, n_colors, 3, padding=1)
         self._caches = {}
-        self.use_winograd = True    # inference path: Winograd F(2x2,3x3) MFMA kernel for the F->F / F->4F convs
+        self.use_winograd = True    # inference path: Winograd MFMA kernels for the F->F / F->4F convs
+        self.use_winograd4 = True   # inference path: F(4x4,3x3) for the layers without PixelShuffle (the residual body); False = F(2x2,3x3)
         self.fuse_upsampler = True   # inference path, x4 only: up1/PS/up2/PS/tail (linear) run as one 5x5 conv + PS4 + the border-class frame launch
         #                              (same outputs, tests/test_fullsize_gpu.py; False = three conv3x3 launches)
         self._fused_up = _FusedUpsampler()
@@ -517,7 +540,8 @@ class SRNet(nn.Module):
 
     def _conv(self, name, conv, x, **kw):
         algo = pick_algo(conv.in_channels, conv.out_channels, 1, x.shape[-1], self.use_winograd,
-                         plain=kw.get("residual") is None and not kw.get("pixel_shuffle"))
+                         plain=kw.get("residual") is None and not kw.get("pixel_shuffle"),
+                         f4=self.use_winograd4 and not kw.get("pixel_shuffle"))
         return conv3x3(x, self._packed(name, conv, algo), conv.out_channels, bias=conv.bias, algo=algo, **kw)
 
     def forward(self, x):

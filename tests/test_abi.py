@@ -182,3 +182,6 @@ def test_pick_algo_routes_layers_to_their_kernels():
     assert pick_algo(5, 64, 1, 250, plain=True) == "direct"          # small-Cin kernel needs W % 4 == 0
     assert pick_algo(64, 64, 1, 256, use_winograd=False) == "direct"
     assert pick_algo(64, 2048, 1, 256) == "winograd"                 # bias vector would not fit the persistent kernel's LDS staging
+    assert pick_algo(64, 64, 1, 256, f4=True) == "winograd4"         # SR body at inference (no PixelShuffle): Winograd F(4x4,3x3)
+    assert pick_algo(64, 64, 1, 254, f4=True) == "winograd"          # ... needs 16-byte aligned rows like the F(2x2) persistent kernel
+    assert pick_algo(3, 64, 1, 256, plain=True, f4=True) == "smallci"
