@@ -175,11 +175,12 @@ class DegradeSRWorkload:
         # dominant kernel: the 33 conv3x3 64->64 launches of the residual body (61 % of the step's FLOPs).
         #   algorithmic FLOPs per launch = 2*9*N*Cin*Cout*H*W;
         #   ISSUED MFMA FLOPs per launch = what the kernel's v_mfma instructions execute: the Winograd F(2x2,3x3) kernels
-        #   need 16 multiplies per 2x2 output tile and (ci, co) pair instead of 36 -> algorithmic / 2.25 at this shape
+        #   need 16 multiplies per 2x2 output tile and (ci, co) pair instead of 36 -> algorithmic / 2.25 at this shape; the
+        #   F(4x4,3x3) kernel ("winograd4", the body's kernel since round 3) 36 per 4x4 tile instead of 144 -> algorithmic / 4
         #   (no channel / tile padding: 64 channels, 256 % 64 == 0).  roofline.frac is issued / peak: <= 1 by construction.
-        self.body_algo = pick_algo(64, 64, 1, w, self.net.use_winograd)
+        self.body_algo = pick_algo(64, 64, 1, w, self.net.use_winograd, f4=self.net.use_winograd4)
         self.body_flops_per_launch = 2.0 * 9 * batch * 64 * 64 * h * w
-        self.body_issue_ratio = {"direct": 1.0, "winograd": 1 / 2.25, "winograd_vreg": 1 / 2.25}[self.body_algo]
+        self.body_issue_ratio = {"direct": 1.0, "winograd": 1 / 2.25, "winograd_vreg": 1 / 2.25, "winograd4": 1 / 4.0}[self.body_algo]
         # degradation kernel: algorithmic bytes per patch = HR read once + LR written once + taps
         self.deg_bytes_per_launch = batch * (4 * C * self.H * self.W + 4 * C * h * w + 4 * C * 13 * 13)
         self._record = False
@@ -189,26 +190,30 @@ class DegradeSRWorkload:
         """The 33 body convs of a step are launched back to back on the launch stream (torch's current stream): ONE HIP event pair
         brackets the run (first launch b0.1 ... last launch body_tail) and the mean launch duration is its elapsed time / 33.
         (An event pair around every single launch drains the queue between kernels and reads 0.38-0.45 ms for a kernel that rocprof
-        times at 0.389 ms; the bracketed run agrees with rocprof.)"""
+        times at 0.389 ms; the bracketed run agrees with rocprof.)  The events are created before the pass (creating them inside a
+        step stalls the host long enough to starve the queue now that a body launch takes < 0.3 ms)."""
         if self._record and name == "b0.1":
-            self._e0 = torch.cuda.Event(enable_timing=True)
-            self._e0.record()
+            self._cur = self._pool.pop()
+            self._cur[0].record()
         out = self._orig_conv(name, conv, x, **kw)
         if self._record and name == "body_tail":
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            self._ev_body.append((self._e0, e1))
+            self._cur[1].record()
+            self._ev_body.append(self._cur)
         return out
 
-    def instrument(self, on):
+    def instrument(self, on, steps=0):
         if on and not hasattr(self, "_orig_conv"):
             self._orig_conv = self.net._conv
             self.net._conv = self._timed_conv
+        if on:
+            mk = lambda: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._pool = [mk() for _ in range(steps + 4)]
+            self._pool_deg = [mk() for _ in range(steps + 4)]
         self._record = on
 
     def step(self):
         if self._record:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = self._pool_deg.pop()
             e0.record()
         kmsr_amd.degrade_batch(self.hr, self.bank, 4, down="stride", pad="zero", normalize=False,
                                kernel_idx=self.kid, sigma=self.sigma, noise="gaussian", seed=42, offset=self.step_no,
@@ -223,44 +228,48 @@ class DegradeSRWorkload:
 
     def roofline(self, _unused_ms):
         n_body = 2 * len(self.net.body) + 1                                   # launches between the two events of a step
-        ms = [a.elapsed_time(b) / n_body for a, b in self._ev_body]
-        kernel_ms = sum(ms) / max(len(ms), 1)
+        ms = sorted(a.elapsed_time(b) / n_body for a, b in self._ev_body)
+        kernel_ms = ms[len(ms) // 2] if ms else float("nan")                  # median over the steps: a host hiccup inside one bracket starves the queue
+        kernel_ms_mean = sum(ms) / max(len(ms), 1)
         algorithmic = self.body_flops_per_launch / (kernel_ms * 1e-3) / 1e12
         issued = algorithmic * self.body_issue_ratio
-        traffic = static_traffic("conv3x3_winov")
+        traffic = static_traffic({"winograd4": "conv3x3_wino4"}.get(self.body_algo, "conv3x3_winov"))
         kname = {"winograd_vreg": "conv3x3_winov_kernel<false>", "winograd": "conv3x3_wino_kernel<false>",
-                 "direct": "conv3x3_mfma_kernel<1,false>"}[self.body_algo]
+                 "direct": "conv3x3_mfma_kernel<1,false>", "winograd4": "conv3x3_wino4_kernel"}[self.body_algo]
+        form = {"winograd4": "Winograd F(4x4,3x3) on the fp32 MFMA: 36 products per 4x4 outputs (direct / 4), one 512-register wave per SIMD, "
+                             "in-lane packed-fp32 transforms, weights L2 -> MFMA operand registers, buffer LDS-DMA raw rows"}.get(
+            self.body_algo, "Winograd F(2x2,3x3) on the fp32 MFMA, persistent workgroups, LDS-DMA rings")
         out = {"bound": "mfma",
-               "kernel": f"{kname} (3x3 conv 64->64 @256x256, batch 16; 33 launches/step; Winograd F(2x2,3x3) on the fp32 MFMA, persistent workgroups, LDS-DMA rings)",
+               "kernel": f"{kname} (3x3 conv 64->64 @256x256, batch 16; 33 launches/step; {form})",
                "achieved": round(issued, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                "frac": round(issued / F32_MFMA_PEAK_TFLOPS, 4),
-               "what": "achieved = MFMA FLOPs the kernel ISSUES per launch (algorithmic direct-conv FLOPs / 2.25 for Winograd F(2x2,3x3)) "
-                       "/ mean launch duration (one HIP event pair per step around the 33 back-to-back body launches on the launch stream, elapsed / 33; instrumented pass of the same steps); frac = matrix-pipe utilisation",
+               "what": f"achieved = MFMA FLOPs the kernel ISSUES per launch (algorithmic direct-conv FLOPs x {self.body_issue_ratio:.4f}: / 2.25 for Winograd F(2x2,3x3), / 4 for F(4x4,3x3)) "
+                       "/ mean launch duration (one HIP event pair per step around the 33 back-to-back body launches on the launch stream, elapsed / 33, median over the steps of an instrumented pass of the same steps); frac = matrix-pipe utilisation",
                "issued_flops_per_launch": self.body_flops_per_launch * self.body_issue_ratio,
                "algorithmic_flops_per_launch": self.body_flops_per_launch,
                "algorithmic_tflops": round(algorithmic, 2),
                "algorithmic_over_peak": round(algorithmic / F32_MFMA_PEAK_TFLOPS, 4),
-               "kernel_ms": round(kernel_ms, 4), "launches_timed": len(ms) * n_body}
+               "kernel_ms": round(kernel_ms, 4), "kernel_ms_mean_over_steps": round(kernel_ms_mean, 4), "launches_timed": len(ms) * n_body}
         out.update(traffic)
         return out
 
     def issued_mfma_flops_per_step(self, fused):
         """MFMA FLOPs one step issues (the degradation and the 64->3 tail are VALU kernels and not counted):
-        Winograd layers = algorithmic / 2.25; head = small-Cin MFMA kernel with the 3 bands padded to 2 channel pairs;
+        body layers = algorithmic x body_issue_ratio (/ 4 on the F(4x4,3x3) kernel), layer-wise upsampler convs = algorithmic / 2.25; head = small-Cin MFMA kernel with the 3 bands padded to 2 channel pairs;
         collapsed upsampler = one 5x5 conv 64 -> 48 per LR pixel (32x32x2 tiles for 32 channels + 16x16x4 tiles for 16: no channel
         padding; + the border-class frame launch, a VALU kernel, not counted)."""
         px = self.B * self.h * self.w
-        body = 33 * 18.0 * 64 * 64 / 2.25
+        body = 33 * 18.0 * 64 * 64 * self.body_issue_ratio
         head = 18.0 * 4 * 64
         up = 50.0 * 64 * 16 * self.C if fused else 18.0 * 64 * 256 * (1 + 4) / 2.25
         return (body + head + up) * px
 
     def roofline_degrade(self):
         """north_star's first target: HBM roofline of the fused degradation kernel, from the launches inside the steps."""
-        ms = [a.elapsed_time(b) for a, b in self._ev_deg]
+        ms = sorted(a.elapsed_time(b) for a, b in self._ev_deg)
         if not ms:
             return None
-        kernel_ms = sum(ms) / len(ms)
+        kernel_ms = ms[len(ms) // 2]
         ach = self.deg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": "degrade_rowstream_kernel (V-B: 13x13 stride 4, zero pad, Philox noise) on HR [16,3,1024,1024]",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -662,7 +671,7 @@ def main():
     if hasattr(wl, "instrument"):
         # per-kernel HIP events (launch stream) in a second pass of the same steps, right after the timed region: the
         # headline carries no event records, the roofline numbers still come from live launches of this run
-        wl.instrument(True)
+        wl.instrument(True, args.steps)
         el_i, _ = timed(args.steps)
         wl.instrument(False)
         instrumented = round(el_i / args.steps * 1e3, 4)

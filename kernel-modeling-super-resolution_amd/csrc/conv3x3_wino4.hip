@@ -12,8 +12,8 @@
 //   * MFMA tile 16 channels x 16 tiles x 4 input channels.  A wave owns 32 output channels x 16 tiles (one tile row of 4x4 tiles =
 //     4 output rows x 64 columns) for ALL 36 transform points: 2 x 36 accumulator tiles x 4 registers = 288 registers
 //     (hipcc keeps them in the AGPR half).  Lane (tile t = lane & 15, channel kq = lane >> 4) supplies the B operand
-//     V[xi][4 s + kq][t] for every xi: exactly the 6x6 input transform B^T d B of ITS patch, which it computes itself (144 VALU per
-//     72 MFMAs) from the raw rows in LDS.  The output transform A^T M A is lane-local too: no exchange, no epilogue barrier.
+//     V[xi][4 s + kq][t] for every xi: exactly the 6x6 input transform B^T d B of ITS patch, which it computes itself (78 packed-fp32
+//     VALU per 72 MFMAs) from the raw rows in LDS.  The output transform A^T M A is lane-local too: no exchange, no epilogue barrier.
 //   * the workgroup = 2 channel halves x 2 tile rows = 64 channels x (8 rows x 64 columns) per item, PERSISTENT over an interleaved
 //     item list; the 4-channel steps of all its items form ONE stream.
 //   * A operands (the pre-transformed weights U = G g G^T, 36 x 64 x 4 floats = 36 KB per step and workgroup) do NOT go through
@@ -115,26 +115,68 @@ __device__ __forceinline__ void q_wait_vm() {       // all but the N newest vect
     Q_FENCE();
 }
 
-// 1-D input transform B^T d (12 VALU):  B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]]
-__device__ __forceinline__ void bt6(float d0, float d1, float d2, float d3, float d4, float d5, float& o0, float& o1, float& o2,
-                                    float& o3, float& o4, float& o5) {
-    const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
-    const float c = d4 - d2, e = d3 - d1;
-    o0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+// ---- packed-fp32 transform helpers.  v_pk_fma_f32 / v_pk_add_f32 cost the SIMD the same ~5 cycles as a scalar v_fma_f32 when
+// clustered between f32 MFMAs (tools/ubench/valu_cluster.hip) but do two lanes of work, and op_sel / neg_hi pick and negate halves
+// for free -- the transforms below are written on register PAIRS throughout.
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// 1-D input transform B^T d on a pair of independent lines (12 packed VALU for 2 x 6 outputs):
+//   B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]]
+__device__ __forceinline__ void bt6p(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2 d5, f32x2& o0, f32x2& o1, f32x2& o2,
+                                     f32x2& o3, f32x2& o4, f32x2& o5) {
+    const f32x2 a = fma2(splat2(-4.f), d2, d4), b = fma2(splat2(-4.f), d1, d3);
+    const f32x2 c = d4 - d2, e = d3 - d1;
+    o0 = fma2(splat2(4.f), d0, fma2(splat2(-5.f), d2, d4));
     o1 = a + b;
     o2 = a - b;
-    o3 = fmaf(2.f, e, c);
-    o4 = fmaf(-2.f, e, c);
-    o5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+    o3 = fma2(splat2(2.f), e, c);
+    o4 = fma2(splat2(-2.f), e, c);
+    o5 = fma2(splat2(4.f), d1, fma2(splat2(-5.f), d3, d5));
 }
-// 1-D output transform A^T m (10 VALU):  A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]
-__device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1, float& y2,
-                                    float& y3) {
-    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+// (x.y + x.x, x.y - x.x)
+__device__ __forceinline__ f32x2 pk_hi_pm_lo(f32x2 x) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(x));
+    return r;
+}
+// (x.x + x.y, x.x - x.y)
+__device__ __forceinline__ f32x2 pk_lo_pm_hi(f32x2 x) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x));
+    return r;
+}
+// (x.y + 2 x.x, x.y - 2 x.x)
+__device__ __forceinline__ f32x2 pk_hi_pm_2lo(f32x2 x) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, 2.0, %1 op_sel:[0,0,1] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(x));
+    return r;
+}
+// (x.y * k.x + w.x, x.x * k.y + w.y): the halves of x swapped
+__device__ __forceinline__ f32x2 pk_fma_swap(f32x2 x, f32x2 k, f32x2 w) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(x), "v"(k), "v"(w));
+    return r;
+}
+// 1-D input transform of ONE line held as the pairs P0 = (t0,t5), P1 = (t1,t2), P2 = (t3,t4) (7 packed VALU):
+//   returns O05 = (o0,o5), O12 = (o1,o2), O34 = (o3,o4).  K41 = (4,1), K54 = (-5,4), K15 = (1,-5).
+__device__ __forceinline__ void bt6row(f32x2 P0, f32x2 P1, f32x2 P2, f32x2 K41, f32x2 K54, f32x2 K15, f32x2& O05, f32x2& O12, f32x2& O34) {
+    const f32x2 BA = fma2(splat2(-4.f), P1, P2);            // (t3 - 4 t1, t4 - 4 t2) = (b, a)
+    const f32x2 EC = P2 - P1;                               // (t3 - t1, t4 - t2)     = (e, c)
+    O12 = pk_hi_pm_lo(BA);                                  // (a + b, a - b)
+    O34 = pk_hi_pm_2lo(EC);                                 // (c + 2e, c - 2e)
+    f32x2 w = P0 * K41;                                     // (4 t0, t5)
+    w = pk_fma_swap(P1, K54, w);                            // (4 t0 - 5 t2, t5 + 4 t1)
+    O05 = pk_fma_swap(P2, K15, w);                          // (4 t0 - 5 t2 + t4, t5 + 4 t1 - 5 t3)
+}
+// 1-D output transform A^T m on a pair of independent lines (10 packed VALU for 2 x 4 outputs):
+//   A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]
+__device__ __forceinline__ void at6p(f32x2 m0, f32x2 m1, f32x2 m2, f32x2 m3, f32x2 m4, f32x2 m5, f32x2& y0, f32x2& y1, f32x2& y2,
+                                     f32x2& y3) {
+    const f32x2 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
     y0 = m0 + s1 + s2;
-    y1 = fmaf(2.f, d2, d1);
-    y2 = fmaf(4.f, s2, s1);
-    y3 = fmaf(8.f, d2, d1) + m5;
+    y1 = fma2(splat2(2.f), d2, d1);
+    y2 = fma2(splat2(4.f), s2, s1);
+    y3 = fma2(splat2(8.f), d2, d1) + m5;
 }
 
 template <bool HAS_RES>
@@ -232,37 +274,47 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     // ---- patch of lane (tile t16, channel kq) in step g: raw rows 4 tg + r (r = 0..5), raw columns 4 t16 + 3 + j (j = 0..5):
     //      one ds_read_b128 (columns 4 t16 + 4 .. + 7, j = 1..4) + one ds_read2_b32 (j = 0 and j = 5) per row.
     const int pbase = kq * QPLANE + (4 * tg) * QRCOLS + 4 * t16 + 3;
-    struct Patch { f32x4 mid[6]; float lo[6], hi[6]; };
+    struct Patch { f32x4 mid[6]; f32x2 e[6]; };             // e = (column 0, column 5)
     auto load_patch = [&](int g) {
         const float* rp = lds + QOFF_R + (g % QNRAW) * QRAWF + pbase;
         Patch P;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             P.mid[r] = *reinterpret_cast<const f32x4*>(rp + r * QRCOLS + 1);
-            P.lo[r] = rp[r * QRCOLS];
-            P.hi[r] = rp[r * QRCOLS + 5];
+            P.e[r] = f32x2{rp[r * QRCOLS], rp[r * QRCOLS + 5]};
         }
         return P;
     };
-    // V = B^T d B: column pass over the 6 patch columns (T[i][j] = sum_r B^T[i][r] d[r][j]), then row pass (V[i][:] = T[i][:] B)
-    auto cols_pass = [&](const Patch& P, float (&t)[6][6]) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            float d[6];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) d[r] = j == 0 ? P.lo[r] : (j == 5 ? P.hi[r] : P.mid[r][j - 1]);
-            bt6(d[0], d[1], d[2], d[3], d[4], d[5], t[0][j], t[1][j], t[2][j], t[3][j], t[4][j], t[5][j]);
-            asm volatile("" : "+v"(t[0][j]), "+v"(t[1][j]), "+v"(t[2][j]), "+v"(t[3][j]), "+v"(t[4][j]), "+v"(t[5][j]));   // keep the VALU work where it is written (LLVM would sink it)
-        }
+    // V = B^T d B.  Column pass (T = B^T d) on the column PAIRS (0,5), (1,2), (3,4) -- the ds_read2_b32 result and the two halves of
+    // the ds_read_b128 quad are already register pairs: 3 x 12 packed VALU.  Row pass (V[i][:] = T[i][:] B) inside each row on the
+    // same pairs: 6 x 7 packed VALU.  78 VALU per patch instead of 144 scalar ones.
+    struct TPairs { f32x2 p0[6], p1[6], p2[6]; };           // per row i: (t0,t5), (t1,t2), (t3,t4)
+    auto cols_pass = [&](const Patch& P, TPairs& t) {
+        bt6p(P.e[0], P.e[1], P.e[2], P.e[3], P.e[4], P.e[5], t.p0[0], t.p0[1], t.p0[2], t.p0[3], t.p0[4], t.p0[5]);
+        asm volatile("" : "+v"(t.p0[0]), "+v"(t.p0[1]), "+v"(t.p0[2]), "+v"(t.p0[3]), "+v"(t.p0[4]), "+v"(t.p0[5]));   // keep the VALU work where it is written
+#define Q_LOHALF(X) f32x2{(X).x, (X).y}
+#define Q_HIHALF(X) f32x2{(X).z, (X).w}
+        bt6p(Q_LOHALF(P.mid[0]), Q_LOHALF(P.mid[1]), Q_LOHALF(P.mid[2]), Q_LOHALF(P.mid[3]), Q_LOHALF(P.mid[4]), Q_LOHALF(P.mid[5]),
+             t.p1[0], t.p1[1], t.p1[2], t.p1[3], t.p1[4], t.p1[5]);
+        asm volatile("" : "+v"(t.p1[0]), "+v"(t.p1[1]), "+v"(t.p1[2]), "+v"(t.p1[3]), "+v"(t.p1[4]), "+v"(t.p1[5]));
+        bt6p(Q_HIHALF(P.mid[0]), Q_HIHALF(P.mid[1]), Q_HIHALF(P.mid[2]), Q_HIHALF(P.mid[3]), Q_HIHALF(P.mid[4]), Q_HIHALF(P.mid[5]),
+             t.p2[0], t.p2[1], t.p2[2], t.p2[3], t.p2[4], t.p2[5]);
+        asm volatile("" : "+v"(t.p2[0]), "+v"(t.p2[1]), "+v"(t.p2[2]), "+v"(t.p2[3]), "+v"(t.p2[4]), "+v"(t.p2[5]));
+#undef Q_LOHALF
+#undef Q_HIHALF
     };
-    auto rows_pass = [&](const float (&t)[6][6], int i0, int i1, float (&v)[QPTS]) {
+    f32x2 K41 = f32x2{4.f, 1.f}, K54 = f32x2{-5.f, 4.f}, K15 = f32x2{1.f, -5.f};
+    asm volatile("" : "+v"(K41), "+v"(K54), "+v"(K15));     // loop-invariant register pairs (not re-materialised per use)
+    auto rows_pass = [&](const TPairs& t, int i0, int i1, float (&v)[QPTS]) {
 #pragma unroll
-        for (int i = i0; i < i1; ++i)
-            bt6(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], v[6 * i + 0], v[6 * i + 1], v[6 * i + 2], v[6 * i + 3],
-                v[6 * i + 4], v[6 * i + 5]);
-#pragma unroll
-        for (int i = i0; i < i1; ++i)
-            asm volatile("" : "+v"(v[6 * i + 0]), "+v"(v[6 * i + 1]), "+v"(v[6 * i + 2]), "+v"(v[6 * i + 3]), "+v"(v[6 * i + 4]), "+v"(v[6 * i + 5]));
+        for (int i = i0; i < i1; ++i) {
+            f32x2 O05, O12, O34;
+            bt6row(t.p0[i], t.p1[i], t.p2[i], K41, K54, K15, O05, O12, O34);
+            asm volatile("" : "+v"(O05), "+v"(O12), "+v"(O34));
+            v[6 * i + 0] = O05.x; v[6 * i + 5] = O05.y;
+            v[6 * i + 1] = O12.x; v[6 * i + 2] = O12.y;
+            v[6 * i + 3] = O34.x; v[6 * i + 4] = O34.y;
+        }
     };
 
     f32x4 acc[2][QPTS];    // [channel block of 16][xi]: rows = channels 4 kq + reg, column = tile t16
@@ -282,7 +334,7 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     float vA[QPTS], vB[QPTS];
     {
         const Patch P = load_patch(0);
-        float t[6][6];
+        TPairs t;
         cols_pass(P, t);
         rows_pass(t, 0, 6, vA);
     }
@@ -315,21 +367,21 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
         q_barrier_lds();                                     // raw(g+1) visible to every wave; raw(g)'s slot free
         issue_raw();                                         // raw(g+3)
         const Patch P = load_patch(g + 1);
-        float t[6][6];
+        TPairs t;
         Q_SB();
         Q_MFMA8(0, vc, FIRST); Q_SB(); load_a(a_cur, 5); Q_SB();
         Q_MFMA8(1, vc, FIRST); Q_SB(); load_a(a_cur, 6); Q_SB();
-        cols_pass(P, t);                                     // 72 VALU
+        cols_pass(P, t);                                     // 36 packed VALU
         Q_SB();
         Q_MFMA8(2, vc, FIRST); Q_SB(); load_a(a_cur, 7); Q_SB();
         Q_MFMA8(3, vc, FIRST); Q_SB(); load_a(a_cur, 8); Q_SB();
         Q_MFMA8(4, vc, FIRST); Q_SB(); load_a(a_nxt, 4); Q_SB();
-        rows_pass(t, 0, 3, vn);                              // 36 VALU
+        rows_pass(t, 0, 3, vn);                              // 21 packed VALU
         Q_SB();
         Q_MFMA8(5, vc, FIRST); Q_SB(); load_a(a_nxt, 0); Q_SB();
         Q_MFMA8(6, vc, FIRST); Q_SB(); load_a(a_nxt, 1); Q_SB();
         Q_MFMA8(7, vc, FIRST); Q_SB(); load_a(a_nxt, 2); Q_SB();
-        rows_pass(t, 3, 6, vn);                              // 36 VALU
+        rows_pass(t, 3, 6, vn);                              // 21 packed VALU
         Q_SB();
         Q_MFMA8(8, vc, FIRST); Q_SB(); load_a(a_nxt, 3); Q_SB();
         advance_a();
@@ -366,18 +418,25 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
             const int cbi = k >> 2, r = k & 3;
             if (k + 2 < 8) fetch(k + 2);
             const float bb = lds[QOFF_B + cg * QCO + (2 * hh + cbi) * 16 + 4 * kq + r];
-            float ma[4][6];                                  // A^T M  (rows of outputs x 6 transform columns)
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-                at6(acc[cbi][0 * 6 + j][r], acc[cbi][1 * 6 + j][r], acc[cbi][2 * 6 + j][r], acc[cbi][3 * 6 + j][r], acc[cbi][4 * 6 + j][r],
-                    acc[cbi][5 * 6 + j][r], ma[0][j], ma[1][j], ma[2][j], ma[3][j]);
+            // A^T M on the column pairs (0,5), (1,2), (3,4): ma?[a] = rows of outputs; 3 x 10 packed VALU
+            f32x2 ma0[4], ma1[4], ma2[4];
+#define Q_M(I, J) acc[cbi][(I) * 6 + (J)][r]
+#define Q_MP(I, J0, J1) f32x2{Q_M(I, J0), Q_M(I, J1)}
+            at6p(Q_MP(0, 0, 5), Q_MP(1, 0, 5), Q_MP(2, 0, 5), Q_MP(3, 0, 5), Q_MP(4, 0, 5), Q_MP(5, 0, 5), ma0[0], ma0[1], ma0[2], ma0[3]);
+            at6p(Q_MP(0, 1, 2), Q_MP(1, 1, 2), Q_MP(2, 1, 2), Q_MP(3, 1, 2), Q_MP(4, 1, 2), Q_MP(5, 1, 2), ma1[0], ma1[1], ma1[2], ma1[3]);
+            at6p(Q_MP(0, 3, 4), Q_MP(1, 3, 4), Q_MP(2, 3, 4), Q_MP(3, 3, 4), Q_MP(4, 3, 4), Q_MP(5, 3, 4), ma2[0], ma2[1], ma2[2], ma2[3]);
+#undef Q_MP
+#undef Q_M
             f32x4 Y[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                float y0_, y1_, y2_, y3_;
-                at6(ma[a][0], ma[a][1], ma[a][2], ma[a][3], ma[a][4], ma[a][5], y0_, y1_, y2_, y3_);
-                Y[a] = f32x4{y0_ + bb, y1_ + bb, y2_ + bb, y3_ + bb};
-                if (p.relu) Y[a] = f32x4{fmaxf(Y[a].x, 0.f), fmaxf(Y[a].y, 0.f), fmaxf(Y[a].z, 0.f), fmaxf(Y[a].w, 0.f)};
+                // (m0,m5), (m1,m2), (m3,m4) -> y0 = m0 + s1 + s2, y1 = d1 + 2 d2, y2 = s1 + 4 s2, y3 = d1 + 8 d2 + m5
+                const f32x2 SD1 = pk_lo_pm_hi(ma1[a]), SD2 = pk_lo_pm_hi(ma2[a]);      // (s1, d1), (s2, d2)
+                f32x2 y01 = fma2(SD2, f32x2{1.f, 2.f}, SD1), y23 = fma2(SD2, f32x2{4.f, 8.f}, SD1);
+                y01 += f32x2{bb, bb};
+                y23 += f32x2{bb, bb};
+                Y[a] = f32x4{y01.x + ma0[a].x, y01.y, y23.x, y23.y + ma0[a].y};
+                if (p.relu) Y[a] = __builtin_elementwise_max(Y[a], f32x4{0.f, 0.f, 0.f, 0.f});
             }
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
