@@ -63,8 +63,6 @@ constexpr int QNA = 5;                  // register slots for A-operand groups: 
 constexpr int QVG = 2;                  // accumulator groups kept in ArchVGPRs (2 x 8 tiles x 4 = 64 registers); the other 7 x 32 = 224 in AGPRs
 constexpr int QMAX_BIAS = 1024;
 constexpr int QOFF_R = 0, QOFF_B = QNRAW * QRAWF, QLDS_FLOATS = QOFF_B + QMAX_BIAS;
-static_assert(QRINSTR * QT * 4 == QRAWF, "every wave issues the same number of DMA instructions");
-
 struct Wino4Params {
     int N, Cin, H, W, Cout;
     int tiles_x, tiles, cgs, nsteps, relu, n_items;
@@ -189,6 +187,7 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     const int hh = wv & 1, tg = wv >> 1;                    // channel half, tile row
     const int H = p.H, W = p.W, S = p.nsteps;
     const long long HW = (long long)H * W;
+    const unsigned HWb = (unsigned)HW * 4u;
 
     // items of this workgroup: vb, vb + nwg, ...  (vb = XCD-grouped id; see conv3x3_wino_vreg.hip: neighbouring tiles run at the
     // same time on the CUs of one XCD, so halo rows are L2 hits)
@@ -203,16 +202,17 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     //      offsets of the step being multiplied and of the one after it.
     const auto urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpk), 0, 0xFFFFFFFFu, 0x00020000);
     const unsigned a_lane = (unsigned)(hh * (QGROUPS * 2 * 256) + lane * 4) * 4u;   // byte offset of this lane inside a step of U
-    int gA = 0, cA = 0, itA = it0;
-    unsigned a_cur = (unsigned)(((it0 / p.tiles) % p.cgs) * S) * (unsigned)(QUF * 4), a_nxt = a_cur;
+    int gN = 0, cA = 0, itA = it0;                           // a_nxt = stream step gN = step cA of item itA
+    auto a_item = [&](int it) { return p.cgs == 1 ? 0u : (unsigned)(((it / p.tiles) % p.cgs) * S) * (unsigned)(QUF * 4); };
+    unsigned a_cur = a_item(it0), a_nxt = a_cur;
     auto advance_a = [&]() {                                // a_cur <- a_nxt <- the step after it (past the end of the stream: stays)
         a_cur = a_nxt;
-        ++gA;
-        if (gA < T) {
+        if (gN + 1 < T) {
+            ++gN;
             if (++cA == S) {
                 cA = 0;
                 itA += istep;
-                a_nxt = (unsigned)(((itA / p.tiles) % p.cgs) * S) * (unsigned)(QUF * 4);
+                a_nxt = a_item(itA);
             } else {
                 a_nxt += (unsigned)(QUF * 4);
             }
@@ -233,21 +233,30 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     //      touching LDS *and* global memory and then drains vmcnt(0) / lgkmcnt(0) at the next counted dependency -- here the first
     //      MFMA that reads a loaded weight register, i.e. a full HBM round trip per step.)
     constexpr unsigned ROOB = 0x80000000u;
-    int gR = 0, cR = 0, itR = it0;
+    int rpk[QRINSTR];                                       // per DMA instruction: this lane's (channel << 16 | row << 8 | quad), -1 = plane padding
+#pragma unroll
+    for (int i = 0; i < QRINSTR; ++i) {
+        const int L = (QRINSTR * wv + i) * 64 + lane;
+        const int ch = L / QPLANE_Q, u = L - ch * QPLANE_Q, row = u / QRQ, q = u - row * QRQ;
+        rpk[i] = u < QRROWS * QRQ ? (ch << 16 | row << 8 | q) : -1;
+    }
+    int gR = 0, cR = 0, itR = it0;                          // next raw request = stream step gR = step cR of item itR
     unsigned roff[QRINSTR];
-    const float* xnR = xg;
-    auto raw_map = [&]() {
+    const float* xstep = xg;                                // first channel of the step to request next
+    int ch_left = 0;                                        // channels from there to the end of the image's channels
+    int wr_off = 0;                                         // ring slot (float offset) the next request lands in
+    auto raw_map = [&]() {                                  // the cursor enters item itR
         const int tile = itR % p.tiles, n = itR / (p.tiles * p.cgs);
         const int ty0 = (tile / p.tiles_x) * (4 * QTR), tx0 = (tile % p.tiles_x) * (4 * QTC);
-        xnR = xg + (long long)n * p.Cin * HW;
-        int lane_o = lane;
-        asm volatile("" : "+v"(lane_o));
+        xstep = xg + (long long)n * p.Cin * HW;
+        ch_left = p.Cin;
 #pragma unroll
         for (int i = 0; i < QRINSTR; ++i) {
-            const int L = (QRINSTR * wv + i) * 64 + lane_o;
-            const int ch = L / QPLANE_Q, u = L - ch * QPLANE_Q, row = u / QRQ, q = u - row * QRQ;
+            int pk = rpk[i];
+            asm volatile("" : "+v"(pk));                     // recompute ch * HW etc. HERE, once per item (hoisted they would be spilled)
+            const int ch = pk >> 16, row = (pk >> 8) & 255, q = pk & 255;
             const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * q;
-            const bool ok = u < QRROWS * QRQ && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+            const bool ok = pk >= 0 && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
             roff[i] = ok ? (unsigned)(ch * (int)HW + gy * W + gx) * 4u : ROOB;
         }
     };
@@ -256,18 +265,20 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
         // one descriptor per (image, step): base = the step's first channel, records = the channels that are left (raw-buffer range
         // checks cover the VGPR offset only, not soffset -- so the channel position lives in the base).  Past the end of the stream:
         // an empty descriptor (every lane out of range -> zeros; that slot is never multiplied).
-        const int ch_left = gR < T ? p.Cin - cR * QCK : 0;
-        const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xnR + (long long)cR * QCK * HW), 0,
-                                                          (unsigned)ch_left * (unsigned)HW * 4u, 0x00020000);
-        float* rb = lds + QOFF_R + (gR % QNRAW) * QRAWF;
+        const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xstep), 0, (unsigned)max(ch_left, 0) * HWb, 0x00020000);
+        float* rb = lds + QOFF_R + wr_off;
 #pragma unroll
         for (int i = 0; i < QRINSTR; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t*)(rb + (QRINSTR * wv + i) * 256), 16, roff[i], 0, 0, 0);
+        wr_off = wr_off == (QNRAW - 1) * QRAWF ? 0 : wr_off + QRAWF;
+        xstep += (long long)QCK * HW;
+        ch_left -= QCK;
         ++gR;
         if (++cR == S) {
             cR = 0;
             itR += istep;
             if (gR < T) raw_map();
+            else ch_left = 0;
         }
     };
 
@@ -275,8 +286,10 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     //      one ds_read_b128 (columns 4 t16 + 4 .. + 7, j = 1..4) + one ds_read2_b32 (j = 0 and j = 5) per row.
     const int pbase = kq * QPLANE + (4 * tg) * QRCOLS + 4 * t16 + 3;
     struct Patch { f32x4 mid[6]; f32x2 e[6]; };             // e = (column 0, column 5)
-    auto load_patch = [&](int g) {
-        const float* rp = lds + QOFF_R + (g % QNRAW) * QRAWF + pbase;
+    int rd_off = 0;                                         // ring slot (float offset) of the patch to read next: raw(0), raw(1), ...
+    auto load_patch = [&]() {
+        const float* rp = lds + QOFF_R + rd_off + pbase;
+        rd_off = rd_off == (QNRAW - 1) * QRAWF ? 0 : rd_off + QRAWF;
         Patch P;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
@@ -331,12 +344,12 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     for (int g = 0; g < QNA; ++g) load_a(a_cur, g);
     q_wait_vm<0>();
     q_barrier_lds();
-    float vA[QPTS], vB[QPTS];
-    {
-        const Patch P = load_patch(0);
+    float vv[QPTS];                                          // V of the step being multiplied; overwritten in place by the next step's V
+    {                                                        // (rows 0-2 once the MFMAs of points 0 .. 19 have issued, rows 3-5 after the last group)
+        const Patch P = load_patch();
         TPairs t;
         cols_pass(P, t);
-        rows_pass(t, 0, 6, vA);
+        rows_pass(t, 0, 6, vv);
     }
 
     // ---- one step: 72 MFMAs on V(cur) / A(cur), next step's A requested group by group into the registers just consumed, next
@@ -349,7 +362,7 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                    \
         _Pragma("unroll") for (int cbi = 0; cbi < 2; ++cbi) {                                                             \
             if constexpr ((G) < QVG) {                                                                                    \
-                if constexpr (FIRST)                                                                                      \
+                if (FIRST)                                                                                                \
                     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc[cbi][4 * (G) + jj]) : "v"(A[(G) % QNA][cbi][jj]), "v"((VC)[4 * (G) + jj])); \
                 else                                                                                                      \
                     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[cbi][4 * (G) + jj]) : "v"(A[(G) % QNA][cbi][jj]), "v"((VC)[4 * (G) + jj])); \
@@ -359,14 +372,41 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
             }                                                                                                             \
         }                                                                                                                 \
     }
-    auto step = [&](int g, const float (&vc)[QPTS], float (&vn)[QPTS], auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
+    // ---- output / skip-tensor addressing of an item: buffer operations on one descriptor per (image, 64-channel group) whose record
+    //      count ends at the group's last real channel: padding channels and out-of-image lanes are dropped by the range check.
+    constexpr unsigned OOB = 0x80000000u;
+    const float* cur_res = res;                              // (image, cout group) of the skip tensor / the output of the item being multiplied
+    float* cur_out = out;
+    unsigned cur_nrec = 0;
+    int cur_cg = 0;
+    unsigned vo_cur[4];                                      // byte offset of (this lane's first channel 2 hh * 16 + 4 kq, row y0 + a, column x0)
+    auto set_item = [&](int item) {
+        const int tile = item % p.tiles, rest = item / p.tiles;
+        const int n = rest / p.cgs, cg = rest % p.cgs;
+        const int y0 = (tile / p.tiles_x) * (4 * QTR) + 4 * tg, x0 = (tile % p.tiles_x) * (4 * QTC) + 4 * t16;
+        const long long go = ((long long)n * p.Cout + cg * QCO) * HW;
+        cur_res = res + go;
+        cur_out = out + go;
+        cur_nrec = (unsigned)min(QCO, p.Cout - cg * QCO) * HWb;
+        cur_cg = cg;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            vo_cur[a] = (x0 < W && y0 + a < H) ? (unsigned)((2 * hh * 16 + 4 * kq) * (int)HW + (y0 + a) * W + x0) * 4u : OOB;
+    };
+    auto koff = [&](int k) { return (unsigned)((k >> 2) * 16 + (k & 3)) * HWb; };      // sub-block k = cbi * 4 + r: channel offset inside the lane's 32
+    set_item(it0);
+
+    // FIRST (an item's first step: accumulators start from zero) is a literal at both call sites and folds after inlining.  (Not a
+    // generic lambda with a tag type: hipcc's host pass then fails to instantiate the <true, true> kernel.)
+    auto step = [&](const bool FIRST) __attribute__((always_inline)) {
+        float (&vc)[QPTS] = vv;
+        float (&vn)[QPTS] = vv;
         // raw(g+1) was requested at the top of step g-2; since then this wave has issued 18 + 3 + 18 vector-memory operations
-        // (+ an item's stores / skip loads, which only makes the count conservative)
+        // (+ an item's stores / skip-tensor requests, which only makes the count conservative)
         q_wait_vm<2 * QGROUPS * 2 + QRINSTR>();
         q_barrier_lds();                                     // raw(g+1) visible to every wave; raw(g)'s slot free
         issue_raw();                                         // raw(g+3)
-        const Patch P = load_patch(g + 1);
+        const Patch P = load_patch();
         TPairs t;
         Q_SB();
         Q_MFMA8(0, vc, FIRST); Q_SB(); load_a(a_cur, 5); Q_SB();
@@ -381,67 +421,63 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
         Q_MFMA8(5, vc, FIRST); Q_SB(); load_a(a_nxt, 0); Q_SB();
         Q_MFMA8(6, vc, FIRST); Q_SB(); load_a(a_nxt, 1); Q_SB();
         Q_MFMA8(7, vc, FIRST); Q_SB(); load_a(a_nxt, 2); Q_SB();
-        rows_pass(t, 3, 6, vn);                              // 21 packed VALU
-        Q_SB();
         Q_MFMA8(8, vc, FIRST); Q_SB(); load_a(a_nxt, 3); Q_SB();
+        rows_pass(t, 3, 6, vn);                              // 21 packed VALU (points 18 .. 35: every MFMA of this step has issued)
+        Q_SB();
         advance_a();
     };
 
-    // ---- epilogue of one item: lane-local output transform, bias / ReLU / skip, 16-byte stores.  Buffer operations on one
-    //      descriptor per (image, 64-channel group): padding channels and out-of-image lanes are dropped by the range check.
-    const unsigned HWb = (unsigned)HW * 4u;
-    constexpr unsigned OOB = 0x80000000u;
-    auto epilogue = [&](int item) {
-        const int tile = item % p.tiles, rest = item / p.tiles;
-        const int n = rest / p.cgs, cg = rest % p.cgs;
-        const int y0 = (tile / p.tiles_x) * (4 * QTR) + 4 * tg, x0 = (tile % p.tiles_x) * (4 * QTC) + 4 * t16;
-        const unsigned nrec = (unsigned)min(QCO, p.Cout - cg * QCO) * HWb;
-        const auto ro = __builtin_amdgcn_make_buffer_rsrc(out + ((long long)n * p.Cout + cg * QCO) * HW, 0, nrec, 0x00020000);
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res) + ((long long)n * p.Cout + cg * QCO) * HW, 0, nrec, 0x00020000);
-        unsigned vo[4];                                      // byte offset of (channel 0 of the group, row y0 + a, column x0)
+    // ---- epilogue of one item: lane-local output transform (A^T M A on register pairs), bias / ReLU / skip.  Sub-block k = cbi * 4 + r
+    //      is one output channel of this lane: 4 rows x 4 columns.
+    auto sub_block = [&](int k, f32x4 (&Y)[4]) {
+        const int cbi = k >> 2, r = k & 3;
+        const float bb = lds[QOFF_B + cur_cg * QCO + (2 * hh + cbi) * 16 + 4 * kq + r];
+        // A^T M on the column pairs (0,5), (1,2), (3,4): ma?[a] = rows of outputs; 3 x 10 packed VALU
+        f32x2 ma0[4], ma1[4], ma2[4];
+#define Q_M(I, J) acc[cbi][(I) * 6 + (J)][r]
+#define Q_MP(I, J0, J1) f32x2{Q_M(I, J0), Q_M(I, J1)}
+        at6p(Q_MP(0, 0, 5), Q_MP(1, 0, 5), Q_MP(2, 0, 5), Q_MP(3, 0, 5), Q_MP(4, 0, 5), Q_MP(5, 0, 5), ma0[0], ma0[1], ma0[2], ma0[3]);
+        at6p(Q_MP(0, 1, 2), Q_MP(1, 1, 2), Q_MP(2, 1, 2), Q_MP(3, 1, 2), Q_MP(4, 1, 2), Q_MP(5, 1, 2), ma1[0], ma1[1], ma1[2], ma1[3]);
+        at6p(Q_MP(0, 3, 4), Q_MP(1, 3, 4), Q_MP(2, 3, 4), Q_MP(3, 3, 4), Q_MP(4, 3, 4), Q_MP(5, 3, 4), ma2[0], ma2[1], ma2[2], ma2[3]);
+#undef Q_MP
+#undef Q_M
 #pragma unroll
-        for (int a = 0; a < 4; ++a) vo[a] = (x0 < W && y0 + a < H) ? (unsigned)((y0 + a) * W + x0) * 4u : OOB;
-        // sub-blocks k = cbi * 4 + r (one output channel of this lane each); skip-tensor rows are requested two sub-blocks ahead
-        f32x4 rr[3][4];
-        auto chan_off = [&](int k) { return (unsigned)((2 * hh + (k >> 2)) * 16 + 4 * kq + (k & 3)) * HWb; };
+        for (int a = 0; a < 4; ++a) {
+            // (m0,m5), (m1,m2), (m3,m4) -> y0 = m0 + s1 + s2, y1 = d1 + 2 d2, y2 = s1 + 4 s2, y3 = d1 + 8 d2 + m5
+            const f32x2 SD1 = pk_lo_pm_hi(ma1[a]), SD2 = pk_lo_pm_hi(ma2[a]);      // (s1, d1), (s2, d2)
+            f32x2 y01 = fma2(SD2, f32x2{1.f, 2.f}, SD1), y23 = fma2(SD2, f32x2{4.f, 8.f}, SD1);
+            y01 += f32x2{bb, bb};
+            y23 += f32x2{bb, bb};
+            Y[a] = f32x4{y01.x + ma0[a].x, y01.y, y23.x, y23.y + ma0[a].y};
+        }
+        if (p.relu) {                                        // block-uniform; the empty asm keeps it a branch (hipcc otherwise emits 16 selects)
+            asm volatile("");
+#pragma unroll
+            for (int a = 0; a < 4; ++a) Y[a] = __builtin_elementwise_max(Y[a], f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+    };
+    auto epilogue = [&]() {
+        const auto ro = __builtin_amdgcn_make_buffer_rsrc(cur_out, 0, cur_nrec, 0x00020000);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cur_res), 0, cur_nrec, 0x00020000);
+        f32x4 rr[3][4];                                      // skip-tensor rows are requested two sub-blocks ahead
         auto fetch = [&](int k) {
             if constexpr (HAS_RES) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
-                    rr[k % 3][a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[a] + chan_off(k), 0, 0));
+                    rr[k % 3][a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo_cur[a] + koff(k), 0, 0));
             }
         };
         fetch(0);
         fetch(1);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int cbi = k >> 2, r = k & 3;
             if (k + 2 < 8) fetch(k + 2);
-            const float bb = lds[QOFF_B + cg * QCO + (2 * hh + cbi) * 16 + 4 * kq + r];
-            // A^T M on the column pairs (0,5), (1,2), (3,4): ma?[a] = rows of outputs; 3 x 10 packed VALU
-            f32x2 ma0[4], ma1[4], ma2[4];
-#define Q_M(I, J) acc[cbi][(I) * 6 + (J)][r]
-#define Q_MP(I, J0, J1) f32x2{Q_M(I, J0), Q_M(I, J1)}
-            at6p(Q_MP(0, 0, 5), Q_MP(1, 0, 5), Q_MP(2, 0, 5), Q_MP(3, 0, 5), Q_MP(4, 0, 5), Q_MP(5, 0, 5), ma0[0], ma0[1], ma0[2], ma0[3]);
-            at6p(Q_MP(0, 1, 2), Q_MP(1, 1, 2), Q_MP(2, 1, 2), Q_MP(3, 1, 2), Q_MP(4, 1, 2), Q_MP(5, 1, 2), ma1[0], ma1[1], ma1[2], ma1[3]);
-            at6p(Q_MP(0, 3, 4), Q_MP(1, 3, 4), Q_MP(2, 3, 4), Q_MP(3, 3, 4), Q_MP(4, 3, 4), Q_MP(5, 3, 4), ma2[0], ma2[1], ma2[2], ma2[3]);
-#undef Q_MP
-#undef Q_M
             f32x4 Y[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                // (m0,m5), (m1,m2), (m3,m4) -> y0 = m0 + s1 + s2, y1 = d1 + 2 d2, y2 = s1 + 4 s2, y3 = d1 + 8 d2 + m5
-                const f32x2 SD1 = pk_lo_pm_hi(ma1[a]), SD2 = pk_lo_pm_hi(ma2[a]);      // (s1, d1), (s2, d2)
-                f32x2 y01 = fma2(SD2, f32x2{1.f, 2.f}, SD1), y23 = fma2(SD2, f32x2{4.f, 8.f}, SD1);
-                y01 += f32x2{bb, bb};
-                y23 += f32x2{bb, bb};
-                Y[a] = f32x4{y01.x + ma0[a].x, y01.y, y23.x, y23.y + ma0[a].y};
-                if (p.relu) Y[a] = __builtin_elementwise_max(Y[a], f32x4{0.f, 0.f, 0.f, 0.f});
-            }
+            sub_block(k, Y);
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 if constexpr (HAS_RES) Y[a] += rr[k % 3][a];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[a]), ro, vo[a] + chan_off(k), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[a]), ro, vo_cur[a] + koff(k), 0, 0);
             }
         }
     };
@@ -449,23 +485,11 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     // ---- the stream
     int item = it0;
     for (int m = 0; m < n_my; ++m) {
-        int g = m * S;
-        step(g, vA, vB, std::true_type{});
-        ++g;
-        int s = 1;
-        for (; s + 1 < S; s += 2) {                         // pairs of steps (V ping-pong)
-            step(g, vB, vA, std::false_type{});
-            step(g + 1, vA, vB, std::false_type{});
-            g += 2;
-        }
-        if (s < S) {                                         // S even: one more step, V ends in vA
-            step(g, vB, vA, std::false_type{});
-        } else {                                             // S odd: the next item's V(0) sits in vB -> move it (block-uniform, rare)
-#pragma unroll
-            for (int i = 0; i < QPTS; ++i) vA[i] = vB[i];
-        }
-        epilogue(item);
+        step(true);
+        for (int s = 1; s < S; ++s) step(false);
+        epilogue();
         item += istep;
+        if (m + 1 < n_my) set_item(item);
     }
 #undef Q_MFMA8
 }
@@ -527,10 +551,8 @@ extern "C" int kmsr_conv3x3_wino4_fwd_f32(const kmsr_conv3x3_desc* d, const floa
     }
     const int grid = (int)std::min<long long>(nitems, cus);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (residual)
-        conv3x3_wino4_kernel<true><<<grid, QT, 0, stream>>>(x, packed_w, bias, residual, out, p);
-    else
-        conv3x3_wino4_kernel<false><<<grid, QT, 0, stream>>>(x, packed_w, bias, residual, out, p);
+    if (residual) conv3x3_wino4_kernel<true><<<grid, QT, 0, stream>>>(x, packed_w, bias, residual, out, p);
+    else conv3x3_wino4_kernel<false><<<grid, QT, 0, stream>>>(x, packed_w, bias, residual, out, p);
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
 }

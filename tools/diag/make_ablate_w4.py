@@ -18,16 +18,16 @@ def build(name, edits):
     objs = " ".join(f"{R}/{o[:-4]}.o" for o in sorted(os.listdir(R)) if o.endswith(".hip") and o != "conv3x3_wino4.hip")
     subprocess.check_call(f"/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 {objs} {d}/conv3x3_wino4.o -o /root/repo/tools/diag/libkmsr_abl_w4_{name}.so", shell=True)
     print("built", name)
-NOA = [("    auto load_a = [&](unsigned step_off, int g) {           // group g of the step at step_off -> slot g % QNA\n#pragma unroll\n        for (int cbi = 0; cbi < 2; ++cbi)",
-        "    auto load_a = [&](unsigned step_off, int g) {\n#pragma unroll\n        for (int cbi = 0; cbi < 2 && (gA == 0 || p.relu == 12345); ++cbi)")]
-NOBAR = [("        q_wait_vm<2 * QGROUPS * 2 + QRINSTR>();\n        q_barrier_lds();                                     // raw(g+1) visible to every wave; raw(g)'s slot free",
-          "        q_wait_vm<2 * QGROUPS * 2 + QRINSTR>();")]
+NOA = [("        for (int cbi = 0; cbi < 2; ++cbi)\n            A[g % QNA][cbi] =", "        for (int cbi = 0; cbi < 2 && (gN == 0 || p.relu == 12345); ++cbi)\n            A[g % QNA][cbi] =")]
+NOBAR = [("        q_wait_vm<2 * QGROUPS * 2 + QRINSTR>();\n        q_barrier_lds();", "        q_wait_vm<2 * QGROUPS * 2 + QRINSTR>();")]
 NORAW = [("        issue_raw();                                         // raw(g+3)", "        if (p.relu == 12345) issue_raw();")]
-NOVALU = [("        cols_pass(P, t);                                     // 36 packed VALU", "        if (p.relu == 12345) cols_pass(P, t);"),
+NOVALU = [("        cols_pass(P, t);                                     // 36 packed VALU", "        if (p.relu == 12345) cols_pass(P, t); else asm volatile(\"\" :: \"v\"(P.mid[0]), \"v\"(P.mid[5]), \"v\"(P.e[3]));"),
           ("        rows_pass(t, 0, 3, vn);                              // 21 packed VALU", "        if (p.relu == 12345) rows_pass(t, 0, 3, vn);"),
-          ("        rows_pass(t, 3, 6, vn);                              // 21 packed VALU", "        if (p.relu == 12345) rows_pass(t, 3, 6, vn); else {\n#pragma unroll\n for (int i = 0; i < QPTS; ++i) vn[i] = vc[i] + P.mid[i % 6].x + P.e[i % 6].y; }")]
-NOEPI = [("        epilogue(item);\n        item += istep;", "        if (p.relu == 12345 || m + 1 == n_my) epilogue(item);\n        item += istep;")]
-ABL = {"noa": NOA, "nobar": NOBAR, "noraw": NORAW, "novalu": NOVALU, "noepi": NOEPI, "mfmaonly": NOA + NOBAR + NORAW + NOVALU + NOEPI,
-       "noa_nobar": NOA + NOBAR, "novalu_noepi": NOVALU + NOEPI}
+          ("        rows_pass(t, 3, 6, vn);                              // 21 packed VALU (points 18 .. 35: every MFMA of this step has issued)", "        if (p.relu == 12345) rows_pass(t, 3, 6, vn);")]
+NOEPI = [("        epilogue();\n", "        if (p.relu == 12345 || m + 1 == n_my) epilogue();\n")]
+NODRAIN = [("            if (have_prev && s_in_item < QSTG_SUB) drain(s_in_item);", "            if (p.relu == 12345 && have_prev && s_in_item < QSTG_SUB) drain(s_in_item);")]
+RAWL2 = [("        xstep += (long long)QCK * HW;\n        ch_left -= QCK;", "        if (p.relu == 12345) { xstep += (long long)QCK * HW; ch_left -= QCK; }")]   # every raw request re-reads the same rows: L2 hits
+ABL = {"noa": NOA, "nobar": NOBAR, "noraw": NORAW, "novalu": NOVALU, "noepi": NOEPI, "nodrain": NODRAIN, "rawl2": RAWL2,
+       "mfmaonly": NOA + NOBAR + NORAW + NOVALU + NOEPI + NODRAIN, "noa_noraw": NOA + NORAW, "novalu_noepi": NOVALU + NOEPI}
 for n in (sys.argv[1:] or ABL):
     build(n, ABL[n])

@@ -29,7 +29,7 @@ for d in sorted(glob.glob(f'{out}/p*/')):
         agg = collections.defaultdict(list)
         meta = None
         for r in csv.DictReader(open(f)):
-            if ksub in r['Kernel_Name']:
+            if ksub in r["Kernel_Name"] and "pack" not in r["Kernel_Name"]:
                 agg[r['Counter_Name']].append(float(r['Counter_Value'])); meta = r
         for k, v in agg.items():
             print('PMC', k, 'n=%d' % len(v), 'mean=%.6g' % (sum(v) / len(v)))

@@ -12,17 +12,18 @@ w = (torch.randn(C, C, 3, 3, generator=g) / 24).cuda()
 b = torch.randn(C, generator=g).cuda()
 out = torch.empty_like(x)
 ref = torch.nn.functional.conv2d(x[:1].double(), w.double(), b.double(), padding=1)
-for algo in ("winograd_vreg", "winograd4"):
+r = torch.randn(N, C, H, W, generator=g).cuda()
+for algo in (sys.argv[1:] or ("winograd_vreg", "winograd4")):
     pw = pack_for(algo, w)
-    for name, kw in (("relu", dict(relu=True)), ("residual", dict(residual=x))):
-        for _ in range(3):
+    for name, kw in (("relu", dict(relu=True)), ("residual", dict(residual=r)), ("relu", dict(relu=True))):
+        for _ in range(30):
             conv3x3(x, pw, C, bias=b, algo=algo, out=out, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20):
+        for _ in range(50):
             conv3x3(x, pw, C, bias=b, algo=algo, out=out, **kw)
         e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 20
+        ms = e0.elapsed_time(e1) / 50
         fl = 2 * 9 * N * C * C * H * W
         issued = fl / (4.0 if algo == "winograd4" else 2.25)
         print(f"{algo:14s} {name:9s} {ms*1e3:8.1f} us   algorithmic {fl/ms/1e9:7.1f} TF/s   issued {issued/ms/1e9:6.1f} TF/s = {issued/ms/1e9/157.3:.3f} of the fp32 MFMA peak")
