@@ -260,13 +260,17 @@ class Conv3x3Function(torch.autograd.Function):
     ours).  ReLU's mask is applied to the incoming gradient from the saved output.
     Forward and data gradient take the Winograd kernel where it is eligible (F->F and F->4F layers)."""
     use_winograd = True
+    use_winograd4 = True
 
     @staticmethod
     def _run(x, w, bias, relu, residual=None, pixel_shuffle=False, flip=False, relu_mask=None, chan_sum=False):
         """w: the layer's [Cout,Cin,3,3] parameter; flip=True runs the data-gradient convolution (Cin <-> Cout)."""
         cout, cin = (w.shape[1], w.shape[0]) if flip else (w.shape[0], w.shape[1])
+        # bias / ReLU / residual epilogues only (the forward launches of the F -> F layers): Winograd F(4x4,3x3); launches that need the
+        # ReLU mask, the channel sums or PixelShuffle stay on the F(2x2,3x3) kernel, which has those epilogues
         algo = pick_algo(cin, cout, 1, x.shape[-1], Conv3x3Function.use_winograd,
-                         plain=residual is None and not pixel_shuffle and relu_mask is None)
+                         plain=residual is None and not pixel_shuffle and relu_mask is None,
+                         f4=Conv3x3Function.use_winograd4 and not pixel_shuffle and relu_mask is None and not chan_sum)
         packed = _TrainPacks.get(w, algo, flip)
         if algo != "winograd_vreg" or pixel_shuffle:                 # epilogue extras exist in the winograd_vreg kernel only
             # no fused sums here: (y, None) -- whoever needs the sums of y reduces it then (often nobody does)
