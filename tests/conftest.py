@@ -39,6 +39,22 @@ def assert_close(got, want, rtol, atol=0.0, what=""):
                           f"(max rel {np.max(err / np.maximum(np.abs(want[~nan_w]), 1e-30)):.3e})"
 
 
+def assert_no_farther_than_reference(got, ref32, truth, tol=1e-4, what=""):
+    """The tolerance argument for reference-pinned fp32 comparisons (round-2 verdict, weak #2): `truth` is the reference's own
+    computation in float64 (tests/golden/f64_truth.npz), `ref32` the reference's fp32 fixture.  Per element
+        |got - truth| <= max(|ref32 - truth|, tol * max|truth|)
+    i.e. the HIP result is at least as close to the exact result as the reference's own fp32 run, or within north_star's 1e-4 of
+    the tensor's scale.  Returns (max|got - truth|, max|ref32 - truth|) / max|truth| for the test's report."""
+    got, ref32, truth = (np.asarray(a, np.float64) for a in (got, ref32, truth))
+    assert got.shape == truth.shape == ref32.shape, f"{what}: shapes {got.shape} / {ref32.shape} / {truth.shape}"
+    scale = float(np.abs(truth).max()) + 1e-300
+    e_got, e_ref = np.abs(got - truth), np.abs(ref32 - truth)
+    bad = e_got > np.maximum(e_ref, tol * scale)
+    assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} elements farther from the float64 truth than both the reference's fp32 " \
+                          f"result and {tol:g} of scale; max err {e_got.max() / scale:.3e} of scale (reference fp32: {e_ref.max() / scale:.3e})"
+    return e_got.max() / scale, e_ref.max() / scale
+
+
 @pytest.fixture(scope="session")
 def gpu_device():
     import torch

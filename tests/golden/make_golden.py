@@ -279,8 +279,9 @@ def main():
             print(f"{f:28s} {os.path.getsize(os.path.join(OUT, f)) / 1024:9.1f} KiB")
 
 
-if __name__ == "__main__" and not ({"--patch-cutter", "--moe-backward", "--kernelgan-train"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--patch-cutter", "--moe-backward", "--kernelgan-train", "--f64-truth"} & set(sys.argv)):
     main()
+    make_f64_truth_golden()
 
 
 def patch_cutter_scene(seed=0, H=700, W=900):
@@ -402,8 +403,10 @@ def _grad_record(out, prefix, named_grads, full):
             out[f"{prefix}full__{name}"] = g.numpy().copy()
 
 
-def make_kernelgan_train_golden():
-    """One iteration of each KernelGAN trainer, run with the reference's own classes and loss functions in the statement
+def make_kernelgan_train_golden(dt=torch.float32):
+    """(dt = torch.float64: the same replay with every module and input cast to double -- returns the gradient records instead of
+    writing the fixture; make_f64_truth_golden stores them as the float64 truth the tolerance tests measure both sides against.)
+    One iteration of each KernelGAN trainer, run with the reference's own classes and loss functions in the statement
     order of muti_kernel/train.py:262-286 and single_kernel/train.py:269-308 (the loops live inside main() and read files from
     H:\\..., so the statements are replayed here on seeded inputs).  Weights: the state_dicts already stored in kernelgan.npz;
     critic: PatchDiscriminator(in_ch=5) under torch.manual_seed(0) (its state_dict is stored in moe_backward.npz as D__*).
@@ -419,12 +422,13 @@ def make_kernelgan_train_golden():
     model.load_state_dict({n[len("muti_sd__"):]: torch.from_numpy(KG[n]) for n in KG.files if n.startswith("muti_sd__")})
     torch.manual_seed(0)
     D = nets.PatchDiscriminator(in_ch=5, base_ch=64, num_blocks=4)
+    model, D = model.to(dt), D.to(dt)
     opt_D = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.999))
     opt_G = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.5, 0.999))
-    patches = torch.from_numpy(KG["muti__x"])                                            # [2,5,64,64]
-    real_ds = landsat_like((2, 5, 8, 8), 41) / 100.0
-    eps = torch.randn(2, 5, 8, 8, generator=torch.Generator().manual_seed(42))
-    target_sigma = torch.tensor([0.55, 0.72, 0.83, 0.63, 0.19])
+    patches = torch.from_numpy(KG["muti__x"]).to(dt)                                     # [2,5,64,64]
+    real_ds = (landsat_like((2, 5, 8, 8), 41) / 100.0).to(dt)
+    eps = torch.randn(2, 5, 8, 8, generator=torch.Generator().manual_seed(42)).to(dt)
+    target_sigma = torch.tensor([0.55, 0.72, 0.83, 0.63, 0.19]).to(dt)
     real_randn_like = torch.randn_like
     torch.randn_like = lambda t, **kw: eps.clone()
     try:
@@ -465,11 +469,12 @@ def make_kernelgan_train_golden():
                        if n.startswith("single_perturbed_sd__")})
     torch.manual_seed(0)
     D = snets.PatchDiscriminator(in_ch=5, base_ch=64, num_blocks=4)
+    G, D = G.to(dt), D.to(dt)
     opt_D = torch.optim.Adam(D.parameters(), lr=4e-4, betas=(0.5, 0.999))
     opt_G = torch.optim.Adam(G.parameters(), lr=4e-4, betas=(0.5, 0.999))
     from torch.nn.utils import clip_grad_norm_
-    patches = landsat_like((2, 5, 64, 64), 31) / 100.0
-    real_ds = landsat_like((2, 5, 8, 8), 43) / 100.0
+    patches = (landsat_like((2, 5, 64, 64), 31) / 100.0).to(dt)
+    real_ds = (landsat_like((2, 5, 8, 8), 43) / 100.0).to(dt)
     fake_ds = G(patches)
     D.train(); G.train()
     loss_D = sloss.lsgan_d_loss(D(real_ds), D(fake_ds.detach()))
@@ -491,6 +496,8 @@ def make_kernelgan_train_golden():
     out["single_fake"] = fake_ds.detach().numpy()
     out["single_after_G__chains.0.0.weight"] = G.chains[0][0].weight.detach().numpy().copy()
     out["single_after_G__chains.1.2.weight"] = G.chains[1][2].weight.detach().numpy().copy()
+    if dt != torch.float32:
+        return out
     # ---------------------------------------------------------------- the trainers' samplers (global torch RNG draw order)
     import tempfile
     sys.path.insert(0, os.path.join(k, "muti_kernel"))
@@ -521,7 +528,78 @@ def make_kernelgan_train_golden():
           "muti losses", out["muti_losses"], "single", out["single_losses"], "reg requires grad:", out["muti_reg_requires_grad"])
 
 
-if __name__ == "__main__" and "--kernelgan-train" in sys.argv:
+def make_f64_truth_golden():
+    """float64 TRUTH for the reference-pinned comparisons whose fp32 tolerance is looser than north_star's 1e-4 (round-2 verdict,
+    weak #2): the reference's OWN classes, cast to double, on the same state_dicts / inputs as the fp32 fixtures.  The tests assert
+    |HIP - truth| <= max(|reference fp32 fixture - truth|, 1e-4 * scale) per element: the HIP path is at least as close to the
+    exact result as the reference's own fp32 run is, or within 1e-4.  Only arrays are stored (f64_truth.npz)."""
+    m = _import_reference()
+    KG = np.load(os.path.join(OUT, "kernelgan.npz"))
+    out = {}
+    with torch.no_grad():
+        dm = m["mnet"].DegradationModel(in_ch=5, mid_ch=32, ks=(7, 5, 3, 1, 1, 1), scale_gain=0.1, noise_init=0.3, noise_max=1.2)
+        dm.load_state_dict({n[len("muti_sd__"):]: torch.from_numpy(KG[n]) for n in KG.files if n.startswith("muti_sd__")})
+        dm = dm.double().eval()
+        x = torch.from_numpy(KG["muti__x"]).double()
+        out["muti__kernels_batch"] = dm.generator.extract_effective_kernels(x, reduce_batch=False).numpy()
+        out["muti__kernels_reduced"] = dm.generator.extract_effective_kernels(x, reduce_batch=True).numpy()
+        out["muti__kernels_noinput"] = dm.generator.extract_effective_kernels(None).numpy()
+        out["muti__forward"] = dm.generator(x).numpy()
+        sg = m["snet"].MultiBandLinearGenerator(in_ch=5, mid_ch=32)
+        sg.load_state_dict({n[len("single_perturbed_sd__"):]: torch.from_numpy(KG[n]) for n in KG.files if n.startswith("single_perturbed_sd__")})
+        sg = sg.double()
+        out["single_perturbed__kernels"] = sg.extract_effective_kernels().numpy()
+        out["single_perturbed__forward"] = sg(landsat_like((2, 5, 64, 64), 31).double()).numpy()
+    # SelectorNet in train mode (train_gemini.py:14-39, batch-statistics BatchNorm) and d kernel_bank of the V-B forward (:107-134)
+    sd = torch.load(f"{REF}/moe_kernels/moe_model.pth", weights_only=True, map_location="cpu")
+    B, C, H, W = 3, 5, 40, 44
+    x = landsat_like((B, C, H, W), 31).double()
+    Gl = torch.randn(B, 10, generator=torch.Generator().manual_seed(33)).double()
+    sel = m["gemini"].SelectorNet(in_ch=5, num_classes=10)
+    sel.load_state_dict({k[len("selector."):]: v for k, v in sd.items() if k.startswith("selector.")})
+    sel = sel.double().train()
+    logits = sel(x)
+    (logits * Gl).sum().backward()
+    out["sel_train_logits"] = logits.detach().numpy()
+    out["sel_d_conv0_w"] = sel.features[0].weight.grad.numpy()
+    out["sel_d_cls_w"] = sel.classifier.weight.grad.numpy()
+    out["sel_d_conv6_w_abs_sum"] = np.array([sel.features[6].weight.grad.abs().sum().item()])
+    out["sel_running_mean1"] = sel.features[1].running_mean.numpy()
+    # d kernel_bank for the weights the fp32 fixture recorded (the Gumbel draw itself is not reproducible in double): the statements of
+    # ContentAdaptiveDegradation.forward :107-134 in float64
+    MB = np.load(os.path.join(OUT, "moe_backward.npz"))
+    G = torch.randn(B, C, 10, 11, generator=torch.Generator().manual_seed(32)).double()
+    kb = sd["kernel_bank"].double().requires_grad_(True)
+    w = torch.from_numpy(MB["weights"]).double()
+    vk = torch.nn.functional.softmax(kb.view(10, C, -1), dim=-1).view(10, C, 13, 13)
+    bk = torch.einsum("bk,kchw->bchw", w, vk)
+    o = torch.nn.functional.conv2d(x.view(1, B * C, H, W), bk.reshape(B * C, 1, 13, 13), padding=6, groups=B * C).view(B, C, H, W)[:, :, ::4, ::4]
+    (o * G).sum().backward()
+    out["d_kernel_bank"] = kb.grad.numpy()
+    # one iteration of each KernelGAN trainer in double: the stored gradient tensors
+    tr = make_kernelgan_train_golden(torch.float64)
+    for k_, v in tr.items():
+        if "full__" in k_ or k_ in ("muti_clean", "single_fake", "muti_losses", "single_losses"):
+            out["train__" + k_] = np.asarray(v, np.float64)
+    out["note"] = np.array("the reference's classes cast to double on the inputs of kernelgan.npz / moe_backward.npz / kernelgan_train.npz "
+                           "(muti_kernel/networks.py:101-202, single_kernel/networks.py:83-157, train_gemini.py:14-39,107-134, "
+                           "muti_kernel/train.py:262-286, single_kernel/train.py:269-308)")
+    np.savez_compressed(os.path.join(OUT, "f64_truth.npz"), **out)
+    print("f64_truth.npz", os.path.getsize(os.path.join(OUT, "f64_truth.npz")) // 1024, "KiB", len(out), "arrays")
+    # how far the reference's own fp32 run is from this truth (max |fp32 fixture - truth| / max |truth|)
+    TR = np.load(os.path.join(OUT, "kernelgan_train.npz"))
+    for k_ in ("muti__kernels_batch", "muti__forward", "single_perturbed__kernels", "single_perturbed__forward"):
+        print(f"  reference fp32 vs float64  {k_:34s} {np.abs(KG[k_] - out[k_]).max() / np.abs(out[k_]).max():.2e}")
+    for k_ in ("sel_train_logits", "sel_d_conv0_w", "sel_d_cls_w", "d_kernel_bank"):
+        print(f"  reference fp32 vs float64  {k_:34s} {np.abs(MB[k_] - out[k_]).max() / np.abs(out[k_]).max():.2e}")
+    for k_ in sorted(out):
+        if k_.startswith("train__") and "full__" in k_:
+            print(f"  reference fp32 vs float64  {k_:60s} {np.abs(TR[k_[7:]] - out[k_]).max() / np.abs(out[k_]).max():.2e}")
+
+
+if __name__ == "__main__" and "--f64-truth" in sys.argv:
+    make_f64_truth_golden()
+elif __name__ == "__main__" and "--kernelgan-train" in sys.argv:
     make_kernelgan_train_golden()
 elif __name__ == "__main__" and "--moe-backward" in sys.argv:
     make_moe_backward_golden()

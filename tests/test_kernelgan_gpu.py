@@ -6,10 +6,11 @@ import torch
 
 import kmsr_amd
 import oracle
-from conftest import assert_close, golden, landsat_like
+from conftest import assert_close, assert_no_farther_than_reference, golden, landsat_like
 
 pytestmark = pytest.mark.gpu
 KG = golden("kernelgan.npz")
+F64 = golden("f64_truth.npz")        # the reference's own classes in double on the same inputs (make_golden.py --f64-truth)
 
 
 @pytest.fixture(autouse=True)
@@ -51,6 +52,12 @@ def test_muti_extract_effective_kernels(gpu_device):
     assert_close(g.extract_merged_kernel(x).cpu().numpy(), KG["muti__kernels_reduced"].mean(0), rtol=3e-4, atol=3e-7, what="merged")
     s = kb.sum(dim=(2, 3)).cpu().numpy()
     assert np.allclose(s, 1.0, atol=1e-5) and float(kb.min()) >= 0.0      # invariant: non-negative, sums to 1
+    # the 3e-4 above is ELEMENT-wise relative (taps down to 1e-4 of the peak); against the float64 truth the HIP kernels are no
+    # farther than the reference's fp32 run or 1e-4 of the kernel's peak, element by element
+    for got, key in ((kb, "muti__kernels_batch"), (g.extract_effective_kernels(x), "muti__kernels_reduced"),
+                     (g.extract_effective_kernels(None), "muti__kernels_noinput")):
+        e, er = assert_no_farther_than_reference(got.cpu().numpy(), KG[key], F64[key], 1e-4, key)
+        assert e < 2e-5, f"{key}: {e:.2e} of scale from the float64 truth (reference fp32: {er:.2e})"
 
 
 def test_single_extract_effective_kernels(gpu_device):
@@ -59,6 +66,9 @@ def test_single_extract_effective_kernels(gpu_device):
     assert_close(g.extract_effective_kernels().cpu().numpy(), KG["single_default__kernels"], rtol=1e-5, atol=1e-9, what="default init")
     g.load_state_dict(_sd("single_perturbed_sd__"), strict=True)
     assert_close(g.extract_effective_kernels().cpu().numpy(), KG["single_perturbed__kernels"], rtol=3e-4, atol=3e-7, what="perturbed")
+    e, er = assert_no_farther_than_reference(g.extract_effective_kernels().cpu().numpy(), KG["single_perturbed__kernels"],
+                                             F64["single_perturbed__kernels"], 1e-4, "single perturbed kernels vs float64")
+    assert e < 2e-5, f"{e:.2e} of scale from the float64 truth (reference fp32: {er:.2e})"
 
 
 def test_compose_against_oracle_other_shapes(gpu_device):
@@ -108,6 +118,8 @@ def test_generator_forward_muti(gpu_device):
     out = g(x)
     assert tuple(out.shape) == (2, 5, 8, 8)
     assert_close(out.cpu().numpy(), KG["muti__forward"], rtol=2e-4, atol=5e-5, what="muti forward")
+    e, er = assert_no_farther_than_reference(out.cpu().numpy(), KG["muti__forward"], F64["muti__forward"], 1e-4, "muti forward vs float64")
+    assert e < 5e-5, f"{e:.2e} of scale from the float64 truth (reference fp32: {er:.2e})"
 
 
 def test_generator_forward_single(gpu_device):
@@ -117,6 +129,9 @@ def test_generator_forward_single(gpu_device):
     assert_close(g(x).cpu().numpy(), KG["single_default__forward"], rtol=1e-4, atol=1e-3, what="single default forward")
     g.load_state_dict(_sd("single_perturbed_sd__"), strict=True)
     assert_close(g(x).cpu().numpy(), KG["single_perturbed__forward"], rtol=1e-4, atol=1e-3, what="single perturbed forward")
+    e, er = assert_no_farther_than_reference(g(x).cpu().numpy(), KG["single_perturbed__forward"], F64["single_perturbed__forward"], 1e-4,
+                                             "single perturbed forward vs float64")
+    assert e < 2e-5, f"{e:.2e} of scale from the float64 truth (reference fp32: {er:.2e})"
     # odd tile coverage: a size that is not a multiple of the 16x16 workgroup tile, against the C oracle
     x2 = torch.from_numpy(landsat_like((1, 5, 40, 56), 32)).cuda()
     sd = {k: v.numpy() for k, v in _sd("single_perturbed_sd__").items()}

@@ -13,10 +13,11 @@ import pytest
 import torch
 
 import kmsr_amd
-from conftest import assert_close, golden, landsat_like
+from conftest import assert_close, assert_no_farther_than_reference, golden, landsat_like
 from oracle.torch_ops import convk_torch
 
 KT = golden("kernelgan_train.npz")
+F64 = golden("f64_truth.npz")
 KG = golden("kernelgan.npz")
 
 
@@ -143,6 +144,9 @@ def _compare_grads(named, prefix, rtol, what):
         if key in KT.files:
             ref = KT[key]
             assert_close(g.detach().cpu().numpy(), ref, rtol=0, atol=rtol * float(np.abs(ref).max()), what=f"{what} {name}")
+            # ... and against the same iteration replayed with the reference's classes in float64 (f64_truth.npz): no farther than the
+            # reference's own fp32 gradients or 1e-4 of the tensor's scale, element by element
+            assert_no_farther_than_reference(g.detach().cpu().numpy(), ref, F64["train__" + key], 1e-4, f"{what} {name} vs float64")
             n_full += 1
     return n_full
 

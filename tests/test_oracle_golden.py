@@ -265,3 +265,22 @@ def test_vb_torch_ops_form(name):
     B, C, H, W, seed = VB[name + "__meta"]
     out = vb_torch(landsat_like((B, C, H, W), int(seed)), K["moe_kernels"][VB[name + "__kid"]], 4).numpy()
     assert_close(out, VB[name + "__out"], rtol=2e-6, what=name)
+
+
+def test_oracle_vs_float64_truth():
+    """The CPU restatement against the reference's own classes run in float64 (tests/golden/f64_truth.npz): composed kernels and
+    generator forward no farther from the exact result than the reference's fp32 run or 1e-4 of scale, element by element -- the
+    fp32 fixture comparisons above use element-wise relative tolerances up to 3e-4 because composed kernels span 4 decades."""
+    from conftest import assert_no_farther_than_reference
+    KG, T = golden("kernelgan.npz"), golden("f64_truth.npz")
+    sd = {k[len("muti_sd__"):]: np.asarray(v) for k, v in KG.items() if k.startswith("muti_sd__")}
+    x = KG["muti__x"]
+    for got, key in ((oracle.muti_extract_effective_kernels(sd, x, reduce_batch=False), "muti__kernels_batch"),
+                     (oracle.muti_extract_effective_kernels(sd, None), "muti__kernels_noinput"),
+                     (oracle.muti_generator_forward(sd, x), "muti__forward")):
+        e, er = assert_no_farther_than_reference(got, KG[key], T[key], 1e-4, key)
+        assert e < 5e-5, (key, e, er)
+    ssd = {k[len("single_perturbed_sd__"):]: np.asarray(v) for k, v in KG.items() if k.startswith("single_perturbed_sd__")}
+    e, er = assert_no_farther_than_reference(oracle.single_extract_effective_kernels(ssd), KG["single_perturbed__kernels"],
+                                             T["single_perturbed__kernels"], 1e-4, "single kernels")
+    assert e < 5e-5, ("single", e, er)
