@@ -185,3 +185,27 @@ def test_pick_algo_routes_layers_to_their_kernels():
     assert pick_algo(64, 64, 1, 256, f4=True) == "winograd4"         # SR body at inference (no PixelShuffle): Winograd F(4x4,3x3)
     assert pick_algo(64, 64, 1, 254, f4=True) == "winograd"          # ... needs 16-byte aligned rows like the F(2x2) persistent kernel
     assert pick_algo(3, 64, 1, 256, plain=True, f4=True) == "smallci"
+
+
+def test_no_wide_store_with_sgpr_soffset():
+    """Round-2's misplaced-dword bug (profiles/r03_soffset_store_hazard.log): on gfx950 a 12- / 16-byte MUBUF store that carries an SGPR
+    soffset needs a wait state before its data VGPRs are overwritten, and hipcc (LLVM's gfx9 hazard table exempts that form) does not
+    insert one.  No kernel may contain the form: compile the kernels that use buffer stores to ISA and grep."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "kernel-modeling-super-resolution_amd", "csrc")
+    pat = re.compile(r"buffer_store_dwordx[34]\s+v\[\d+:\d+\],\s*v\d+,\s*s\[\d+:\d+\],\s*s\d+")
+    with tempfile.TemporaryDirectory() as td:
+        for f in ("conv3x3_wino_vreg.hip", "conv3x3_wino4.hip", "conv3x3_smallci.hip"):
+            out = os.path.join(td, f + ".s")
+            subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-fno-slp-vectorize", "-w", "-S",
+                                   "--cuda-device-only", "-o", out, os.path.join(csrc, f)], stderr=subprocess.DEVNULL)
+            isa = open(out).read()
+            assert "buffer_store_dword" in isa, f
+            bad = pat.findall(isa)
+            assert not bad, f"{f}: wide buffer store with an SGPR soffset: {bad[:2]}"

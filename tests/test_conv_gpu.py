@@ -187,6 +187,23 @@ def test_conv3x3_winograd4_is_deterministic_and_matches_f2(gpu_device):
     assert float((y4a - y2).abs().max()) < 2e-5 * float(y2.abs().max())
 
 
+def test_pixelshuffle_every_element_written_once(gpu_device):
+    """tools/diag/dbg_ps.py as a test (round-2 advisor): conv 64 -> 256 + fused PixelShuffle on a 24x40 image into an output pre-filled
+    with NaN: every element written, every element right.  This is the launch on which an SGPR soffset on the second PixelShuffle row's
+    16-byte store put the NEXT store's first dword into the current one (missing wait state, profiles/r03_soffset_store_hazard.log)."""
+    from kmsr_amd.sr import pack_for
+    torch.manual_seed(0)
+    N, Cin, H, W, Cout = 1, 64, 24, 40, 256
+    x = torch.randn(N, Cin, H, W)
+    w = torch.randn(Cout, Cin, 3, 3) * 0.05
+    ref = F.pixel_shuffle(F.conv2d(x.double(), w.double(), padding=1), 2)
+    for algo in ("winograd_vreg", "winograd", "direct"):
+        out = torch.full((N, Cout // 4, 2 * H, 2 * W), float("nan"), device=gpu_device)
+        conv3x3(x.cuda(), pack_for(algo, w.cuda()), Cout, pixel_shuffle=True, algo=algo, out=out)
+        assert not bool(torch.isnan(out).any()), f"{algo}: unwritten output elements"
+        assert float((out.cpu().double() - ref).abs().max()) < 2e-5 * float(ref.abs().max()), algo
+
+
 SMALLCI_CASES = [  # N, Cin, H, W, Cout, bias, relu
     (2, 3, 24, 40, 64, True, False),        # the SR head (3 bands), partial column tile
     (1, 5, 17, 132, 64, True, True),        # 5 bands (padded to 3 channel pairs), odd height, 3 column tiles
