@@ -311,6 +311,19 @@ int kmsr_conv5x5_ps4_pack_weights_f32(const float* w /* [Cout,Cin,5,5] */, int32
 int kmsr_conv5x5_ps4_fwd_f32(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, const float* x,
                              const float* packed_w, const float* bias, float* out, void* stream);
 
+/* bf16 form of the collapsed x4 upsampler for the channels-last bf16 path (BASELINE config 4): x [N,H,W,Cin_p] bf16 (Cin_p % 16 == 0),
+ * w the composed 5x5 weights [Cout,Cin,5,5] fp32 (rounded to bf16 by the pack kernel), bias fp32 [Cout] or NULL, Cout = 16 * bands;
+ * out bf16 PLANES [N, bands, 4H, 4W] with out[n, co>>4, 4y+((co>>2)&3), 4x+(co&3)] = bias[co] + conv5x5(x, w)[co] (zero pad 2, fp32
+ * accumulation on v_mfma_f32_32x32x16_bf16, one rounding to bf16 at the store).  Replaces three bf16 launches (up1 / up2 / tail) and
+ * their two HR-sized intermediates; the outer HR frame, where the intermediate layers' zero padding differs from the composed
+ * operator's, is recomputed by the caller layer by layer on four border strips (kmsr_amd/sr_bf16.py).
+ * Packed layout [ceil(Cout/64)][Cin_p/16][25 taps][64][16]. */
+size_t kmsr_conv5x5_ps4_bf16_packed_weight_elems(int32_t Cin_p, int32_t Cout);
+int kmsr_conv5x5_ps4_bf16_pack_weights(const float* w /* [Cout,Cin,5,5] */, int32_t Cin, int32_t Cout, int32_t Cin_p, void* packed,
+                                       void* stream);
+int kmsr_conv5x5_ps4_fwd_bf16(int32_t N, int32_t Cin_p, int32_t H, int32_t W, int32_t Cout, const void* x, const void* packed_w,
+                              const float* bias, void* out, void* stream);
+
 /* Outer frame of the collapsed upsampler: on the outermost LR row / column the chain's intermediate zero padding turns the
  * interior 5x5 map into 8 border-class maps (0 top, 1 bottom, 2 left, 3 right -- corners excluded --, 4..7 the corners tl, tr,
  * bl, br).  wcls [8][Cin][25][16*bands] (tap = dy*5+dx, out channel = band*16 + 4a + b), bcls [8][16*bands]; for every border LR

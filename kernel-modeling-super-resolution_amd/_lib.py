@@ -108,6 +108,9 @@ SYMBOLS = {
     "kmsr_conv5x5_ps4_packed_weight_floats": (_sz, [_i32, _i32]),
     "kmsr_conv5x5_ps4_pack_weights_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "kmsr_conv5x5_ps4_fwd_f32": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "kmsr_conv5x5_ps4_bf16_packed_weight_elems": (_sz, [_i32, _i32]),
+    "kmsr_conv5x5_ps4_bf16_pack_weights": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "kmsr_conv5x5_ps4_fwd_bf16": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "kmsr_upsampler_frame_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "kmsr_conv_reflect_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "kmsr_convk_fwd_f32": (C.c_int, [C.POINTER(ConvKDesc), _vp, _vp, _vp, _vp, _vp]),

@@ -138,12 +138,51 @@ class Conv3x3BF16Function(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def conv5x5_ps4_bf16(x, packed_w, cout, bias=None, out=None):
+    """x [N,H,W,Cin_p] bf16 channels-last -> bf16 planes [N, cout/16, 4H, 4W] (kmsr_conv5x5_ps4_fwd_bf16: the collapsed x4 upsampler)."""
+    lib = L.load()
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.ndim == 4
+    N, H, W, cin_p = x.shape
+    assert packed_w.dtype == torch.bfloat16 and packed_w.numel() == lib.kmsr_conv5x5_ps4_bf16_packed_weight_elems(cin_p, int(cout))
+    oshape = (N, cout // 16, 4 * H, 4 * W)
+    if out is None:
+        out = torch.empty(oshape, device=x.device, dtype=torch.bfloat16)
+    else:
+        assert tuple(out.shape) == oshape and out.is_contiguous() and out.dtype == torch.bfloat16
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == cout and bias.is_cuda
+    with torch.cuda.device(x.device):
+        L.check(lib.kmsr_conv5x5_ps4_fwd_bf16(N, cin_p, H, W, int(cout), L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(out),
+                                              L.current_stream()))
+    return out
+
+
+def pack_conv5x5_ps4_weight_bf16(w5, cin_p):
+    """composed 5x5 weights [16*bands, F, 5, 5] fp32 -> the bf16 pack of kmsr_conv5x5_ps4_fwd_bf16."""
+    lib = L.load()
+    w = w5.detach().to(torch.float32).contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    packed = torch.empty(lib.kmsr_conv5x5_ps4_bf16_packed_weight_elems(cin_p, cout), device=w.device, dtype=torch.bfloat16)
+    with torch.cuda.device(w.device):
+        L.check(lib.kmsr_conv5x5_ps4_bf16_pack_weights(L.ptr(w), cin, cout, cin_p, L.ptr(packed), L.current_stream()))
+    return packed
+
+
 class SRNetBF16:
     """bf16 executor of an SRNet (weights are packed once from the module's fp32 parameters; call .refresh() after
-    changing them)."""
+    changing them).
+
+    fuse_upsampler (default, x4 nets): up1 -> PS -> up2 -> PS -> tail (no non-linearity) runs as ONE bf16 conv5x5 + PixelShuffle(4)
+    launch on the composed weights (sr.compose_upsampler, float64 on the host, rounded to bf16 once), writing the [N,bands,4h,4w]
+    output directly; the outer 4-pixel HR frame -- where up2's and tail's own zero padding reach, so the composed operator does not
+    apply -- is recomputed layer by layer on four 4-pixel-wide LR border strips and copied over the interior launch's output
+    (bit-identical there to the layer-by-layer path).  The result is [N,C,4h,4w] bf16 planes; with fuse_upsampler = False (or other
+    scales / tiny inputs) the three layers run one by one and the result is a channels-last view."""
+    FUSE_MIN_SIZE = 8
 
     def __init__(self, net):
         self.net = net
+        self.fuse_upsampler = True
         self.refresh()
 
     def _prep(self, conv, cin_p, cout_p):
@@ -163,6 +202,12 @@ class SRNetBF16:
         self.body_tail = self._prep(n.body_tail, F, F)
         self.up = [self._prep(u, F, 4 * F) for u in n.up]
         self.tail = self._prep(n.tail, F, _pad16(n.n_colors))
+        self.up5 = None
+        if len(n.up) == 2:
+            from .sr import compose_upsampler
+            w5, b5 = compose_upsampler(n.up[0], n.up[1], n.tail)
+            dev = n.tail.weight.device
+            self.up5 = (pack_conv5x5_ps4_weight_bf16(w5.to(dev), F), b5.to(dev).contiguous(), w5.shape[0])
 
     @torch.no_grad()
     def __call__(self, x):
@@ -175,6 +220,27 @@ class SRNetBF16:
         for c1, c2 in self.body:
             h = cv(c2, cv(c1, h, relu=True), residual=h)
         h = cv(self.body_tail, h, residual=f)
+        if self.fuse_upsampler and self.up5 is not None and min(h.shape[1:3]) >= self.FUSE_MIN_SIZE:
+            return self._fused_upsampler(h)
+        return from_nhwc(self._layerwise_upsampler(h), n.n_colors)
+
+    def _layerwise_upsampler(self, h):
+        cv = lambda prm, t, **kw: conv3x3_bf16(t, prm[0], prm[2], bias=prm[1], **kw)
         for u in self.up:
             h = cv(u, h, pixel_shuffle=True)
-        return from_nhwc(cv(self.tail, h), n.n_colors)
+        return cv(self.tail, h)
+
+    def _fused_upsampler(self, h):
+        """h [N,H,W,F] bf16 channels-last -> [N,bands,4H,4W] bf16 planes."""
+        C = self.net.n_colors
+        out = conv5x5_ps4_bf16(h, self.up5[0], self.up5[2], bias=self.up5[1])
+        # the outer HR frame (one LR row / column = 4 HR pixels) from the layers themselves: a 4-wide LR strip holds everything
+        # the frame's pixels depend on (HR rows 0..3 <- 4x rows 0..4 <- 2x rows 0..3 <- LR rows 0..2)
+        N, H, W = h.shape[0], h.shape[1], h.shape[2]
+        tb = self._layerwise_upsampler(torch.cat((h[:, :4], h[:, H - 4:]), dim=0))            # top and bottom strips as one batch: [2N,16,4W,Cp]
+        lr = self._layerwise_upsampler(torch.cat((h[:, :, :4], h[:, :, W - 4:]), dim=0))      # left and right: [2N,4H,16,Cp]
+        out[:, :, :4, :] = tb[:N, :4, :, :C].permute(0, 3, 1, 2)
+        out[:, :, 4 * H - 4:, :] = tb[N:, 12:, :, :C].permute(0, 3, 1, 2)
+        out[:, :, :, :4] = lr[:N, :, :4, :C].permute(0, 3, 1, 2)
+        out[:, :, :, 4 * W - 4:] = lr[N:, :, 12:, :C].permute(0, 3, 1, 2)
+        return out

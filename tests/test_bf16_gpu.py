@@ -136,3 +136,61 @@ def test_bf16_backward_rejects_unsupported(gpu_device):
     dy = torch.zeros(1, 8, 32, 256, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(NotImplementedError):          # F -> 4F layer: the gradient conv would read 256 channels (kernel limit 64)
         conv3x3_dgrad_bf16(dy, pack_conv3x3_weight_bf16_dgrad(w, 64, 256), 64)
+
+
+PS4_CASES = [  # N, F, H, W, bands
+    (1, 64, 16, 32, 7),      # config 4's bands: 112 sub-pixel channels = a full 64-channel group + 48
+    (2, 64, 13, 45, 3),      # ragged tiles, 48 channels in one group
+    (1, 32, 9, 70, 1),       # two 16-channel chunks, one band, three column tiles
+    (1, 64, 40, 36, 5),
+]
+
+
+@pytest.mark.parametrize("N,Fc,H,W,bands", PS4_CASES)
+def test_conv5x5_ps4_bf16_vs_torch(N, Fc, H, W, bands, gpu_device):
+    """kmsr_conv5x5_ps4_fwd_bf16 (the collapsed x4 upsampler of the bf16 path) against the fp32 conv of the bf16-rounded operands +
+    PixelShuffle(4), rounded to bf16: within one bf16 ulp everywhere (K = 25 * F products accumulated in fp32 in another order), output
+    pre-filled with NaN: every element written."""
+    from kmsr_amd.sr_bf16 import conv5x5_ps4_bf16, pack_conv5x5_ps4_weight_bf16
+    g = torch.Generator().manual_seed(Fc + 10 * bands + H)
+    x = torch.randn(N, Fc, H, W, generator=g)
+    w5 = torch.randn(16 * bands, Fc, 5, 5, generator=g) / (5.0 * Fc ** 0.5)
+    b5 = torch.randn(16 * bands, generator=g)
+    ref = _bf(F.pixel_shuffle(F.conv2d(_bf(x), _bf(w5), b5, padding=2), 4))
+    out = torch.full((N, bands, 4 * H, 4 * W), float("nan"), device=gpu_device, dtype=torch.bfloat16)
+    conv5x5_ps4_bf16(to_nhwc_bf16(x.cuda(), Fc), pack_conv5x5_ps4_weight_bf16(w5.cuda(), Fc), 16 * bands, bias=b5.cuda(), out=out)
+    got = out.float().cpu()
+    assert not bool(torch.isnan(got).any()), "unwritten output elements"
+    err = (got - ref).abs()
+    ulp = ref.abs().clamp_min(1e-3) * 2.0 ** -7
+    assert bool((err <= ulp).all()), f"max err {float(err.max()):.4g}"
+    assert float((err == 0).float().mean()) > 0.97
+
+
+@pytest.mark.parametrize("colors,shape", [(7, (1, 7, 40, 72)), (3, (2, 3, 16, 24))])
+def test_srnet_bf16_fused_upsampler(colors, shape, gpu_device):
+    """SRNetBF16.fuse_upsampler: the outer 4-pixel HR frame (recomputed layer by layer on four LR border strips) is bit-identical to
+    the layer-by-layer path; the interior (one conv5x5 + PixelShuffle(4) launch on the composed weights, no bf16 rounding of the two
+    intermediate feature maps) agrees with it at the bf16-storage level and is at least as close to the fp32 oracle."""
+    torch.manual_seed(3)
+    ref = SRNetTorch(colors, 64, 2, 4).eval()
+    net = kmsr_amd.SRNet(colors, 64, 2, 4)
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda().eval()
+    ex = SRNetBF16(net)
+    x = torch.rand(*shape) * 2 - 1
+    ex.fuse_upsampler = False
+    lay = ex(x.cuda()).float().cpu()
+    ex.fuse_upsampler = True
+    fus = ex(x.cuda())
+    assert fus.is_contiguous() and tuple(fus.shape) == (shape[0], colors, 4 * shape[2], 4 * shape[3])
+    fus = fus.float().cpu()
+    ring = torch.ones_like(lay, dtype=torch.bool)
+    ring[:, :, 4:-4, 4:-4] = False
+    assert torch.equal(fus[ring], lay[ring]), "the frame must be the layer-by-layer result"
+    with torch.no_grad():
+        want = ref(x)
+    scale = float(want.abs().max())
+    e_f, e_l = float((fus - want).abs().max()) / scale, float((lay - want).abs().max()) / scale
+    assert e_f < 3e-2 and e_f <= 1.25 * e_l + 4e-3, f"fused {e_f:.3e} vs layer-wise {e_l:.3e} of scale from the fp32 oracle"
+    assert float((fus - lay).abs().max()) < 3e-2 * scale

@@ -251,6 +251,48 @@ def test_config3_training_step_fullsize(gpu_device):
 
 
 # ------------------------------------------------------------------------------------------------ config 4
+def test_config4_bf16_fused_upsampler_fullsize(gpu_device):
+    """Config 4's tile through SRNetBF16 with the collapsed upsampler (one bf16 conv5x5 + PixelShuffle(4) launch + border strips) and
+    layer by layer: (1) the outer 4-pixel HR frame is bit-identical (it IS the layer-by-layer computation, on four LR strips);
+    (2) the collapsed launch alone, on the bf16 trunk features of the full tile: windows (four corners' interiors, an edge, the centre,
+    tile seams) within one bf16 ulp of the fp32 conv5x5 of the bf16-rounded operands + PixelShuffle(4), > 97 % bit-identical;
+    (3) fused vs layer-wise over the whole 4096^2 output: <= 3e-2 of scale (the layer-wise path rounds two intermediate maps to bf16)."""
+    from kmsr_amd.sr import compose_upsampler
+    from kmsr_amd.sr_bf16 import SRNetBF16, conv5x5_ps4_bf16
+    torch.manual_seed(0)
+    net = SRNet(7, 64, 16, 4).cuda().eval()
+    ex = SRNetBF16(net)
+    g = torch.Generator(device="cuda").manual_seed(4000)
+    lr = torch.rand(1, 7, 1024, 1024, device="cuda", generator=g) * 80 + 20
+    ex.fuse_upsampler = False
+    lay = ex(lr)
+    ex.fuse_upsampler = True
+    fus = ex(lr)
+    assert tuple(fus.shape) == (1, 7, 4096, 4096) and fus.is_contiguous()
+    ring = torch.ones(4096, 4096, dtype=torch.bool, device="cuda")
+    ring[4:-4, 4:-4] = False
+    assert torch.equal(fus[..., ring], lay[..., ring]), "frame differs from the layer-by-layer result"
+    scale = float(lay.float().abs().max())
+    assert float((fus.float() - lay.float()).abs().max()) < 3e-2 * scale
+    # (2) the collapsed launch on known features
+    bf = lambda t: t.to(torch.bfloat16).float()
+    h = torch.randn(1, 1024, 1024, 64, device="cuda", generator=g).to(torch.bfloat16)
+    w5, b5 = compose_upsampler(net.up[0], net.up[1], net.tail)
+    out = conv5x5_ps4_bf16(h, ex.up5[0], ex.up5[2], bias=ex.up5[1])
+    hc = h.float().permute(0, 3, 1, 2)
+    w5r, b5c = bf(w5).cpu(), b5.cpu()
+    same = []
+    for (wy, wx) in [(0, 0), (992, 992), (0, 500), (500, 37), (250, 992), (120, 120)]:
+        ya, yb, xa, xb = max(wy - 2, 0), min(wy + 34, 1024), max(wx - 2, 0), min(wx + 34, 1024)
+        pad = (2 - (wx - xa), 2 - (xb - wx - 32), 2 - (wy - ya), 2 - (yb - wy - 32))     # zero padding only at the image border
+        ref = bf(F.pixel_shuffle(F.conv2d(F.pad(hc[:, :, ya:yb, xa:xb].cpu(), pad), w5r, b5c), 4))
+        got = out[:, :, 4 * wy:4 * wy + 128, 4 * wx:4 * wx + 128].float().cpu()
+        err = (got - ref).abs()
+        assert bool((err <= ref.abs().clamp_min(1e-3) * 2.0 ** -7).all()), f"window {(wy, wx)}: max err {float(err.max()):.4g}"
+        same.append(float((err == 0).float().mean()))
+    assert min(same) > 0.97, same
+
+
 def test_config4_bf16_fullsize_tile(gpu_device):
     """SRNetBF16 on BASELINE config 4's tile [1,7,1024,1024] -> [1,7,4096,4096]:
       (1) tile independence, bit-exact: a crop of the LR tile (plus the network's receptive-field halo) gives exactly the
