@@ -272,8 +272,8 @@ int kmsr_conv3x3_winov_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int
                                         void* stream);
 int kmsr_conv3x3_winov_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
                                const float* residual, float* out, void* stream);
-/* Winograd F(4x4,3x3) kernel (the SR net's F -> F body layers at inference; stride 1, bias / ReLU / residual epilogues, no
- * PixelShuffle, no flags).  36 multiplies per 4x4 output block and (ci, co) pair instead of 64 for F(2x2,3x3) and 144 direct:
+/* Winograd F(4x4,3x3) kernel (the SR net's F -> F and F -> 4F layers; stride 1; this entry point: bias / ReLU / residual /
+ * PixelShuffle epilogues, flags = 0).  36 multiplies per 4x4 output block and (ci, co) pair instead of 64 for F(2x2,3x3) and 144 direct:
  * 4x fewer MFMA FLOPs issued than the direct form.  Arithmetic stays fp32; the transforms with the points {0, +-1, +-2, inf}
  * re-associate the sums: <= 2e-5 of the output scale vs float64 in the tests (measured 5e-6 .. 8e-6 for a 64 -> 64 layer).
  * One persistent 4-wave workgroup per CU (one 512-register wave per SIMD) walks (image, cout group, 8x64-pixel tile) items as one
@@ -286,6 +286,14 @@ int kmsr_conv3x3_wino4_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int
                                         void* stream);
 int kmsr_conv3x3_wino4_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
                                const float* residual, float* out, void* stream);
+/* The same kernel with the F(2x2) kernel's other epilogues: d->pixel_shuffle (fused PixelShuffle(2), no residual), and the training
+ * step's extras exactly as kmsr_conv3x3_winov_fwd_ex_f32 defines them: KMSR_CONV_FLAG_RELU_MASK (out = residual > 0 ? conv : 0) and,
+ * when chan_sum != NULL, per-channel partial sums of the stored tensor: chan_sum[item][2 tile rows][64] with
+ * item = (n * ceil(Cout/64) + cg) * tiles + tile (kmsr_conv3x3_wino4_chan_sum_floats(d) floats, every entry written, padding
+ * channels 0); summing over (n, tile, tile row) gives sum_{n,y,x} out[n,c,y,x].  Fixed order: run-to-run identical. */
+size_t kmsr_conv3x3_wino4_chan_sum_floats(const kmsr_conv3x3_desc* d);
+int kmsr_conv3x3_wino4_fwd_ex_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
+                                  const float* residual, float* out, float* chan_sum, void* stream);
 /* Training-step variant: honours KMSR_CONV_FLAG_RELU_MASK and, when chan_sum != NULL (not with pixel_shuffle), also writes
  * per-channel partial sums of the tensor it stores: chan_sum[item][4][64] with item = (n * ceil(Cout/64) + cg) * tiles + tile
  * (kmsr_conv3x3_winov_chan_sum_floats(d) floats, every entry written, padding channels 0).  Summing over (n, tile, 4) gives

@@ -66,7 +66,11 @@ constexpr int QOFF_R = 0, QOFF_B = QNRAW * QRAWF, QLDS_FLOATS = QOFF_B + QMAX_BI
 struct Wino4Params {
     int N, Cin, H, W, Cout;
     int tiles_x, tiles, cgs, nsteps, relu, n_items;
+    int res_mask;                       // W4_TRAIN: the skip tensor is a ReLU-mask source: out = res > 0 ? conv : 0 (instead of conv + res)
 };
+// epilogue families: bias / ReLU / residual; + fused PixelShuffle(2) (no residual); + the training step's extras (ReLU-mask form of the
+// skip tensor, per-channel sums of the stored tensor) -- same semantics as conv3x3_wino_vreg.hip's PS / TRAIN instantiations
+enum { W4_PLAIN = 0, W4_PS = 1, W4_TRAIN = 2 };
 
 // packed[cg][step][hh][grp][cbi][lane][jj] = (G g G^T)[xi = 4 grp + jj]  for
 // (co, ci) = (cg*64 + hh*32 + cbi*16 + (lane & 15), step*4 + (lane >> 4)), zero padded; xi = 6 i + j.
@@ -177,10 +181,11 @@ __device__ __forceinline__ void at6p(f32x2 m0, f32x2 m1, f32x2 m2, f32x2 m3, f32
     y3 = fma2(splat2(8.f), d2, d1) + m5;
 }
 
-template <bool HAS_RES>
+template <bool HAS_RES, int MODE>
 __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __restrict__ xg, const float* __restrict__ wpk,
                                                               const float* __restrict__ bias, const float* __restrict__ res,
-                                                              float* __restrict__ out, Wino4Params p) {
+                                                              float* __restrict__ out, float* __restrict__ csum, Wino4Params p) {
+    static_assert(!(HAS_RES && MODE == W4_PS), "no skip tensor together with PixelShuffle");
     __shared__ __attribute__((aligned(16))) float lds[QLDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, t16 = lane & 15, kq = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -378,20 +383,32 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     const float* cur_res = res;                              // (image, cout group) of the skip tensor / the output of the item being multiplied
     float* cur_out = out;
     unsigned cur_nrec = 0;
-    int cur_cg = 0;
+    int cur_cg = 0, cur_item = it0;
     unsigned vo_cur[4];                                      // byte offset of (this lane's first channel 2 hh * 16 + 4 kq, row y0 + a, column x0)
     auto set_item = [&](int item) {
         const int tile = item % p.tiles, rest = item / p.tiles;
         const int n = rest / p.cgs, cg = rest % p.cgs;
         const int y0 = (tile / p.tiles_x) * (4 * QTR) + 4 * tg, x0 = (tile % p.tiles_x) * (4 * QTC) + 4 * t16;
-        const long long go = ((long long)n * p.Cout + cg * QCO) * HW;
-        cur_res = res + go;
-        cur_out = out + go;
-        cur_nrec = (unsigned)min(QCO, p.Cout - cg * QCO) * HWb;
         cur_cg = cg;
+        cur_item = item;
+        if constexpr (MODE == W4_PS) {
+            // conv channel q -> out[n, q >> 2, 2y + (q >> 1 & 1), 2x + (q & 1)]: the group's 64 conv channels are 16 output planes of
+            // 2H x 2W; this lane's four channels 4 kq .. 4 kq + 3 of a block are ONE plane (hh * 8 + cbi * 4 + kq)
+            const int ocs = p.Cout >> 2;
+            cur_out = out + ((long long)n * ocs + cg * 16) * (4 * HW);
+            cur_nrec = (unsigned)min(16, ocs - cg * 16) * 4u * HWb;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-            vo_cur[a] = (x0 < W && y0 + a < H) ? (unsigned)((2 * hh * 16 + 4 * kq) * (int)HW + (y0 + a) * W + x0) * 4u : OOB;
+            for (int a = 0; a < 4; ++a)
+                vo_cur[a] = (x0 < W && y0 + a < H) ? (unsigned)((hh * 8 + kq) * 4 * (int)HW + 2 * (y0 + a) * (2 * W) + 2 * x0) * 4u : OOB;
+        } else {
+            const long long go = ((long long)n * p.Cout + cg * QCO) * HW;
+            cur_res = res + go;
+            cur_out = out + go;
+            cur_nrec = (unsigned)min(QCO, p.Cout - cg * QCO) * HWb;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                vo_cur[a] = (x0 < W && y0 + a < H) ? (unsigned)((2 * hh * 16 + 4 * kq) * (int)HW + (y0 + a) * W + x0) * 4u : OOB;
+        }
     };
     auto koff = [&](int k) { return (unsigned)((k >> 2) * 16 + (k & 3)) * HWb; };      // sub-block k = cbi * 4 + r: channel offset inside the lane's 32
     set_item(it0);
@@ -456,28 +473,77 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
             for (int a = 0; a < 4; ++a) Y[a] = __builtin_elementwise_max(Y[a], f32x4{0.f, 0.f, 0.f, 0.f});
         }
     };
+    auto row_sum16 = [&](float v) {      // sum over the 16 lanes of a DPP row (= the 16 tiles of this wave), valid in lane 15 of the row
+#define Q_ROW_SHR(SH) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + SH, 0xf, 0xf, true))
+        Q_ROW_SHR(1); Q_ROW_SHR(2); Q_ROW_SHR(4); Q_ROW_SHR(8);
+#undef Q_ROW_SHR
+        return v;
+    };
     auto epilogue = [&]() {
         const auto ro = __builtin_amdgcn_make_buffer_rsrc(cur_out, 0, cur_nrec, 0x00020000);
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cur_res), 0, cur_nrec, 0x00020000);
-        f32x4 rr[3][4];                                      // skip-tensor rows are requested two sub-blocks ahead
-        auto fetch = [&](int k) {
-            if constexpr (HAS_RES) {
+        if constexpr (MODE == W4_PS) {
+            // sub-block pairs (r = 2 dy, 2 dy + 1) of a channel block are the two interleaved columns of HR row 2 (y0 + a) + dy:
+            // 8 consecutive floats = two 16-byte stores per (a, dy)
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    rr[k % 3][a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo_cur[a] + koff(k), 0, 0));
+            for (int kp = 0; kp < 4; ++kp) {
+                const int cbi = kp >> 1, dy = kp & 1;
+                f32x4 Y0[4], Y1[4];
+                sub_block(4 * cbi + 2 * dy, Y0);
+                sub_block(4 * cbi + 2 * dy + 1, Y1);
+                const unsigned ko = (unsigned)(cbi * 4) * 4u * HWb + (unsigned)(dy * 2 * W) * 4u;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{Y0[a].x, Y1[a].x, Y0[a].y, Y1[a].y}), ro, vo_cur[a] + ko, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{Y0[a].z, Y1[a].z, Y0[a].w, Y1[a].w}), ro, vo_cur[a] + ko + 16u, 0, 0);
+                }
             }
-        };
-        fetch(0);
-        fetch(1);
+        } else {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cur_res), 0, cur_nrec, 0x00020000);
+            f32x4 rr[3][4];                                  // skip-tensor rows are requested two sub-blocks ahead
+            auto fetch = [&](int k) {
+                if constexpr (HAS_RES) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (k + 2 < 8) fetch(k + 2);
-            f32x4 Y[4];
-            sub_block(k, Y);
+                    for (int a = 0; a < 4; ++a)
+                        rr[k % 3][a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo_cur[a] + koff(k), 0, 0));
+                }
+            };
+            fetch(0);
+            fetch(1);
+            float cs[8];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if constexpr (HAS_RES) Y[a] += rr[k % 3][a];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[a]), ro, vo_cur[a] + koff(k), 0, 0);
+            for (int k = 0; k < 8; ++k) {
+                if (k + 2 < 8) fetch(k + 2);
+                f32x4 Y[4];
+                sub_block(k, Y);
+                float ssum = 0.f;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if constexpr (HAS_RES) {
+                        if (MODE == W4_TRAIN && p.res_mask) {     // block-uniform
+                            const f32x4 m = rr[k % 3][a];
+                            Y[a] = f32x4{m.x > 0.f ? Y[a].x : 0.f, m.y > 0.f ? Y[a].y : 0.f, m.z > 0.f ? Y[a].z : 0.f, m.w > 0.f ? Y[a].w : 0.f};
+                        } else {
+                            Y[a] += rr[k % 3][a];
+                        }
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[a]), ro, vo_cur[a] + koff(k), 0, 0);
+                    if constexpr (MODE == W4_TRAIN) {
+                        if (vo_cur[a] != OOB) ssum += (Y[a].x + Y[a].y) + (Y[a].z + Y[a].w);
+                    }
+                }
+                if constexpr (MODE == W4_TRAIN) {
+                    const int co = cur_cg * QCO + (2 * hh + (k >> 2)) * 16 + 4 * kq + (k & 3);
+                    cs[k] = row_sum16(co < p.Cout ? ssum : 0.f);
+                }
+            }
+            // per-channel sums of what this wave just stored (the bias gradient of the layer that consumes this tensor as its output
+            // gradient): 16 tiles reduced in the DPP row, two float4 per (item, tile row, 4-channel group); fixed order -> run-to-run identical
+            if constexpr (MODE == W4_TRAIN) {
+                if (csum && t16 == 15) {                      // csum: block-uniform
+                    float* o = csum + ((long long)cur_item * QTR + tg) * QCO + 2 * hh * 16 + 4 * kq;
+                    *reinterpret_cast<f32x4*>(o) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+                    *reinterpret_cast<f32x4*>(o + 16) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+                }
             }
         }
     };
@@ -516,13 +582,28 @@ extern "C" int kmsr_conv3x3_wino4_pack_weights_f32(const float* w, int32_t Cin, 
     return KMSR_OK;
 }
 
+extern "C" size_t kmsr_conv3x3_wino4_chan_sum_floats(const kmsr_conv3x3_desc* d) {
+    if (!d || d->N <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return 0;
+    return (size_t)ceil_div(d->W, 4 * QTC) * ceil_div(d->H, 4 * QTR) * ceil_div(d->Cout, QCO) * d->N * QTR * QCO;
+}
+
 extern "C" int kmsr_conv3x3_wino4_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
                                           const float* residual, float* out, void* stream_) {
+    return kmsr_conv3x3_wino4_fwd_ex_f32(d, x, packed_w, bias, residual, out, nullptr, stream_);
+}
+
+extern "C" int kmsr_conv3x3_wino4_fwd_ex_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
+                                             const float* residual, float* out, float* chan_sum, void* stream_) {
     if (!d) return fail(KMSR_E_BADARG, "null descriptor");
-    if (d->flags) return fail(KMSR_E_BADARG, "winograd-4x4 conv takes no flags (0x%x)", d->flags);
+    if (d->flags & ~(uint32_t)KMSR_CONV_FLAG_RELU_MASK) return fail(KMSR_E_BADARG, "unknown conv flags 0x%x", d->flags);
+    if ((d->flags & KMSR_CONV_FLAG_RELU_MASK) && (!residual || d->relu || d->pixel_shuffle))
+        return fail(KMSR_E_BADARG, "KMSR_CONV_FLAG_RELU_MASK needs the mask tensor in `residual` and no relu / pixel_shuffle");
+    if (chan_sum && d->pixel_shuffle) return fail(KMSR_E_UNSUPPORTED, "channel sums are not produced together with pixel_shuffle");
+    if (reinterpret_cast<uintptr_t>(chan_sum) % 16) return fail(KMSR_E_BADARG, "chan_sum must be 16-byte aligned");
     if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return fail(KMSR_E_BADARG, "bad conv shape");
     if (d->stride != 1) return fail(KMSR_E_UNSUPPORTED, "winograd conv needs stride 1");
-    if (d->pixel_shuffle) return fail(KMSR_E_UNSUPPORTED, "winograd-4x4 conv has no PixelShuffle epilogue");
+    if (d->pixel_shuffle && (d->Cout % 4)) return fail(KMSR_E_SHAPE, "pixel_shuffle needs Cout %% 4 == 0 (Cout=%d)", d->Cout);
+    if (d->pixel_shuffle && residual) return fail(KMSR_E_BADARG, "residual is not supported together with pixel_shuffle");
     if (d->W % 4) return fail(KMSR_E_UNSUPPORTED, "winograd-4x4 conv needs W %% 4 == 0 (W=%d): rows move as aligned 16-byte pieces", d->W);
     if (!x || !packed_w || !out) return fail(KMSR_E_BADARG, "null tensor pointer");
     if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(packed_w) % 16 || reinterpret_cast<uintptr_t>(out) % 16 ||
@@ -540,6 +621,7 @@ extern "C" int kmsr_conv3x3_wino4_fwd_f32(const kmsr_conv3x3_desc* d, const floa
     p.cgs = ceil_div(d->Cout, QCO);
     p.nsteps = ceil_div(d->Cin, QCK);
     p.relu = d->relu;
+    p.res_mask = (d->flags & KMSR_CONV_FLAG_RELU_MASK) ? 1 : 0;
     if ((long long)p.cgs * p.nsteps * QUF * 4 >= (1ll << 32)) return fail(KMSR_E_UNSUPPORTED, "packed weights exceed 4 GB");
     const long long nitems = (long long)p.tiles * p.cgs * d->N;
     if (nitems > (1ll << 30)) return fail(KMSR_E_UNSUPPORTED, "conv grid too large");
@@ -551,8 +633,12 @@ extern "C" int kmsr_conv3x3_wino4_fwd_f32(const kmsr_conv3x3_desc* d, const floa
     }
     const int grid = (int)std::min<long long>(nitems, cus);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (residual) conv3x3_wino4_kernel<true><<<grid, QT, 0, stream>>>(x, packed_w, bias, residual, out, p);
-    else conv3x3_wino4_kernel<false><<<grid, QT, 0, stream>>>(x, packed_w, bias, residual, out, p);
+    if (d->pixel_shuffle) conv3x3_wino4_kernel<false, W4_PS><<<grid, QT, 0, stream>>>(x, packed_w, bias, residual, out, nullptr, p);
+    else if (chan_sum || p.res_mask) {
+        if (residual) conv3x3_wino4_kernel<true, W4_TRAIN><<<grid, QT, 0, stream>>>(x, packed_w, bias, residual, out, chan_sum, p);
+        else conv3x3_wino4_kernel<false, W4_TRAIN><<<grid, QT, 0, stream>>>(x, packed_w, bias, residual, out, chan_sum, p);
+    } else if (residual) conv3x3_wino4_kernel<true, W4_PLAIN><<<grid, QT, 0, stream>>>(x, packed_w, bias, residual, out, nullptr, p);
+    else conv3x3_wino4_kernel<false, W4_PLAIN><<<grid, QT, 0, stream>>>(x, packed_w, bias, residual, out, nullptr, p);
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
 }

@@ -80,8 +80,8 @@ def pick_algo(cin, cout, stride, width, use_winograd=True, plain=False, f4=False
     """Kernel for a stride-1 3x3 conv of this shape: the persistent LDS-DMA Winograd kernel when rows are 16-byte aligned
     (W % 4 == 0) and the bias vector fits its LDS staging (Cout <= 1024), the register-staged Winograd kernel for other even
     widths, the direct MFMA / VALU kernels otherwise.  plain=True (no residual, no PixelShuffle) lets layers with <= 8 input
-    channels take the small-Cin kernel.  f4=True (the caller has a bias / ReLU / residual epilogue only: no PixelShuffle, no
-    training extras) lets aligned layers take the Winograd F(4x4,3x3) kernel (4x fewer MFMA FLOPs than direct, 2.25x for F(2x2))."""
+    channels take the small-Cin kernel.  f4=True lets aligned layers take the Winograd F(4x4,3x3) kernel (4x fewer MFMA FLOPs than
+    direct, 2.25x for F(2x2); same epilogues: residual, PixelShuffle, ReLU mask, channel sums)."""
     if plain and stride == 1 and cin <= 8 and cout >= 32 and width % 4 == 0:
         return "smallci"
     if not (use_winograd and winograd_eligible(cin, cout, stride, width)):
@@ -132,15 +132,13 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     d = L.Conv3x3Desc()
     d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, Cin, H, W, int(cout), int(stride)
     d.relu, d.pixel_shuffle = int(bool(relu)), int(bool(pixel_shuffle))
-    if (relu_mask is not None or chan_sum) and algo != "winograd_vreg":
-        raise NotImplementedError("relu_mask / chan_sum are epilogues of the winograd_vreg kernel")
+    if (relu_mask is not None or chan_sum) and algo not in ("winograd_vreg", "winograd4"):
+        raise NotImplementedError("relu_mask / chan_sum are epilogues of the winograd_vreg / winograd4 kernels")
     if relu_mask is not None:
         assert residual is None and not relu and not pixel_shuffle
         residual = relu_mask
         d.flags = L.CONV_FLAG_RELU_MASK
     wino = algo in ("winograd", "winograd_vreg", "winograd4")
-    if algo == "winograd4" and pixel_shuffle:
-        raise NotImplementedError("the Winograd F(4x4,3x3) kernel has no PixelShuffle epilogue")
     if wino and stride != 1:
         raise NotImplementedError("winograd conv needs stride 1")
     need = {"direct": lib.kmsr_conv3x3_packed_weight_floats, "winograd": lib.kmsr_conv3x3_wino_packed_weight_floats,
@@ -162,16 +160,17 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
         if algo == "winograd4" and residual.data_ptr() % 16:
             residual = residual.clone()
     with torch.cuda.device(x.device):
+        ex = lib.kmsr_conv3x3_wino4_fwd_ex_f32 if algo == "winograd4" else lib.kmsr_conv3x3_winov_fwd_ex_f32
         if chan_sum:
-            part = torch.empty(lib.kmsr_conv3x3_winov_chan_sum_floats(d), device=x.device, dtype=torch.float32)
-            L.check(lib.kmsr_conv3x3_winov_fwd_ex_f32(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out),
-                                                      L.ptr(part), L.current_stream()))
+            nsum = (lib.kmsr_conv3x3_wino4_chan_sum_floats if algo == "winograd4" else lib.kmsr_conv3x3_winov_chan_sum_floats)(d)
+            part = torch.empty(nsum, device=x.device, dtype=torch.float32)
+            L.check(ex(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out), L.ptr(part), L.current_stream()))
             cgs = (cout + 63) // 64                  # part[n][cg][tile][4][64] -> per-channel totals
             return out, part.view(N, cgs, -1, 64).sum(dim=(0, 2)).reshape(-1)[:cout]
         fwd = {"direct": lib.kmsr_conv3x3_fwd_f32, "winograd": lib.kmsr_conv3x3_wino_fwd_f32,
-               "winograd4": lib.kmsr_conv3x3_wino4_fwd_f32,
-               "winograd_vreg": lib.kmsr_conv3x3_winov_fwd_ex_f32 if d.flags else lib.kmsr_conv3x3_winov_fwd_f32}[algo]
-        if algo == "winograd_vreg" and d.flags:
+               "winograd4": ex if d.flags else lib.kmsr_conv3x3_wino4_fwd_f32,
+               "winograd_vreg": ex if d.flags else lib.kmsr_conv3x3_winov_fwd_f32}[algo]
+        if algo in ("winograd_vreg", "winograd4") and d.flags:
             L.check(fwd(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out), None, L.current_stream()))
         else:
             L.check(fwd(d, L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(residual), L.ptr(out), L.current_stream()))
@@ -266,13 +265,12 @@ class Conv3x3Function(torch.autograd.Function):
     def _run(x, w, bias, relu, residual=None, pixel_shuffle=False, flip=False, relu_mask=None, chan_sum=False):
         """w: the layer's [Cout,Cin,3,3] parameter; flip=True runs the data-gradient convolution (Cin <-> Cout)."""
         cout, cin = (w.shape[1], w.shape[0]) if flip else (w.shape[0], w.shape[1])
-        # bias / ReLU / residual epilogues only (the forward launches of the F -> F layers): Winograd F(4x4,3x3); launches that need the
-        # ReLU mask, the channel sums or PixelShuffle stay on the F(2x2,3x3) kernel, which has those epilogues
+        # forward and data-gradient launches of the F -> F and F -> 4F layers: Winograd F(4x4,3x3) (it has every epilogue of the F(2x2)
+        # kernel: residual, PixelShuffle, ReLU mask, channel sums)
         algo = pick_algo(cin, cout, 1, x.shape[-1], Conv3x3Function.use_winograd,
-                         plain=residual is None and not pixel_shuffle and relu_mask is None,
-                         f4=Conv3x3Function.use_winograd4 and not pixel_shuffle and relu_mask is None and not chan_sum)
+                         plain=residual is None and not pixel_shuffle and relu_mask is None, f4=Conv3x3Function.use_winograd4)
         packed = _TrainPacks.get(w, algo, flip)
-        if algo != "winograd_vreg" or pixel_shuffle:                 # epilogue extras exist in the winograd_vreg kernel only
+        if algo not in ("winograd_vreg", "winograd4") or pixel_shuffle:     # the training extras exist in these two kernels only (never with PS)
             # no fused sums here: (y, None) -- whoever needs the sums of y reduces it then (often nobody does)
             y = conv3x3(x, packed, cout, bias=bias, relu=relu, residual=residual, pixel_shuffle=pixel_shuffle, algo=algo)
             if relu_mask is not None:
@@ -531,7 +529,7 @@ class SRNet(nn.Module):
         self.tail = nn.Conv2d(n_feats, n_colors, 3, padding=1)
         self._caches = {}
         self.use_winograd = True    # inference path: Winograd MFMA kernels for the F->F / F->4F convs
-        self.use_winograd4 = True   # inference path: F(4x4,3x3) for the layers without PixelShuffle (the residual body); False = F(2x2,3x3)
+        self.use_winograd4 = True   # inference path: F(4x4,3x3) for the aligned F->F / F->4F layers; False = F(2x2,3x3)
         self.fuse_upsampler = True   # inference path, x4 only: up1/PS/up2/PS/tail (linear) run as one 5x5 conv + PS4 + the border-class frame launch
         #                              (same outputs, tests/test_fullsize_gpu.py; False = three conv3x3 launches)
         self._fused_up = _FusedUpsampler()
@@ -545,7 +543,7 @@ class SRNet(nn.Module):
     def _conv(self, name, conv, x, **kw):
         algo = pick_algo(conv.in_channels, conv.out_channels, 1, x.shape[-1], self.use_winograd,
                          plain=kw.get("residual") is None and not kw.get("pixel_shuffle"),
-                         f4=self.use_winograd4 and not kw.get("pixel_shuffle"))
+                         f4=self.use_winograd4)
         return conv3x3(x, self._packed(name, conv, algo), conv.out_channels, bias=conv.bias, algo=algo, **kw)
 
     def forward(self, x):

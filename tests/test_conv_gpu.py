@@ -165,10 +165,56 @@ def test_conv3x3_winograd4_vs_torch(N, Cin, H, W, Cout, bias, relu, res, gpu_dev
     # |ref| + mean|ref| the 6x6-point transforms need 1e-4 (the F(2x2) kernels: 2e-5) -- both inside north_star's 1e-4 relative
     assert float((out.cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), "norm-wise 2e-5 of the output scale"
     _check(out, ref, tol=1e-4, what=f"winograd4 {Cin}->{Cout} {H}x{W}")
-    with pytest.raises(NotImplementedError):            # W % 4 != 0 / PixelShuffle are served by the other kernels
+    with pytest.raises(NotImplementedError):            # W % 4 != 0 is served by the other kernels
         conv3x3(torch.zeros(1, Cin, 4, 6, device=gpu_device), pack_for("winograd4", w.cuda()), Cout, algo="winograd4")
-    with pytest.raises(NotImplementedError):
-        conv3x3(x.cuda(), pack_for("winograd4", w.cuda()), Cout, pixel_shuffle=True, algo="winograd4")
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,bias,relu", [(1, 64, 24, 40, 256, True, False), (2, 16, 9, 68, 36, False, True),
+                                                       (1, 64, 130, 68, 128, True, True), (1, 20, 3, 4, 32, True, False)])
+def test_conv3x3_winograd4_pixelshuffle(N, Cin, H, W, Cout, bias, relu, gpu_device):
+    """Fused PixelShuffle(2) epilogue of the F(4x4,3x3) kernel (out[n, q >> 2, 2y + (q >> 1 & 1), 2x + (q & 1)]), output pre-filled
+    with NaN: every element written; incl. a cout group with 36 channels = 9 output planes and the 24x40 / Cout 256 launch."""
+    from kmsr_amd.sr import pack_for
+    g = torch.Generator().manual_seed(19 * N + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g) if bias else None
+    ref = _ref_conv(x, w, b, relu, None, True)
+    out = torch.full((N, Cout // 4, 2 * H, 2 * W), float("nan"), device=gpu_device)
+    conv3x3(x.cuda(), pack_for("winograd4", w.cuda()), Cout, bias=None if b is None else b.cuda(), relu=relu, pixel_shuffle=True,
+            algo="winograd4", out=out)
+    assert not bool(torch.isnan(out).any()), "unwritten output elements"
+    assert float((out.cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout", [(2, 64, 40, 72, 64), (1, 24, 9, 132, 70), (3, 64, 16, 64, 128)])
+def test_conv3x3_winograd4_training_epilogues(N, Cin, H, W, Cout, gpu_device):
+    """The training step's extras on the F(4x4,3x3) kernel, same semantics as the F(2x2) kernel's: relu_mask (out = mask > 0 ? conv : 0),
+    chan_sum (per-channel sums of what was stored, from the launch's own epilogue), both together, and a residual with sums."""
+    from kmsr_amd.sr import pack_for
+    g = torch.Generator().manual_seed(23 * N + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    m = torch.randn(N, Cout, H, W, generator=g)
+    pw = pack_for("winograd4", w.cuda())
+    conv = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    scale = float(conv.abs().max())
+    # mask + sums
+    y, s = conv3x3(x.cuda(), pw, Cout, bias=b.cuda(), relu_mask=m.cuda(), chan_sum=True, algo="winograd4")
+    ref = torch.where(m.double() > 0, conv, torch.zeros_like(conv))
+    assert float((y.cpu().double() - ref).abs().max()) <= 2e-5 * scale
+    rs = ref.sum(dim=(0, 2, 3))
+    assert float((s.cpu().double() - rs).abs().max()) <= 1e-4 * float(ref.abs().sum(dim=(0, 2, 3)).max())
+    assert float((s.cpu().double() - y.double().sum(dim=(0, 2, 3)).cpu()).abs().max()) <= 1e-5 * float(ref.abs().sum(dim=(0, 2, 3)).max())
+    # residual + sums; mask without sums; bit-reproducible
+    y2, s2 = conv3x3(x.cuda(), pw, Cout, bias=b.cuda(), residual=m.cuda(), chan_sum=True, algo="winograd4")
+    assert float((y2.cpu().double() - (conv + m.double())).abs().max()) <= 2e-5 * float((conv + m.double()).abs().max())
+    assert float((s2.cpu().double() - (conv + m.double()).sum(dim=(0, 2, 3))).abs().max()) <= 1e-4 * float((conv + m.double()).abs().sum(dim=(0, 2, 3)).max())
+    y3 = conv3x3(x.cuda(), pw, Cout, bias=b.cuda(), relu_mask=m.cuda(), algo="winograd4")
+    assert torch.equal(y3, y)
+    y4, s4 = conv3x3(x.cuda(), pw, Cout, bias=b.cuda(), relu_mask=m.cuda(), chan_sum=True, algo="winograd4")
+    assert torch.equal(y4, y) and torch.equal(s4, s)
 
 
 def test_conv3x3_winograd4_is_deterministic_and_matches_f2(gpu_device):
