@@ -505,7 +505,7 @@ def secondary_lines(device, rank, world, kd, sync):
                     "issued_mfma_tflops_per_gpu": rf["achieved"], "frac_of_f32_mfma_peak": rf["frac"],
                     "algorithmic_tflops_per_gpu": rf["algorithmic_tflops"],
                     "grad_allreduce": "none (1 rank)" if world == 1 else f"{wl.bucket.flat.numel() * 4} B fp32 in {len(wl.bucket._slices)} "
-                                      f"slices over RCCL, upper slice launched from a backward hook"}
+                                      f"slices over {torch.distributed.get_backend()} (nccl = RCCL), upper slice launched from a backward hook"}
     del wl
     torch.cuda.empty_cache()
     # ---- config 4: 7-band x4 SR of one 1024x1024 LR tile in bf16 (each rank its own tile)

@@ -11,7 +11,7 @@ ours = lambda names: sorted({n.split("(")[0][:100] for n in names if "kmsr" in n
 k_trace, k_fetch, k_write = ours(s["name"] for s in sm["stats"]), ours(sm["pmc"]["FETCH_SIZE"]), ours(sm["pmc"]["WRITE_SIZE"])
 if not (k_trace == k_fetch == k_write):
     sys.exit(f"kernel lists differ between the trace and the PMC passes -- not the same build / command:\n trace {k_trace}\n fetch {k_fetch}\n write {k_write}")
-keys = {v: [k for k in sm["pmc"]["FETCH_SIZE"] if f"conv3x3_wino4_kernel<{v}>" in k] for v in ("false", "true")}
+keys = {v: [k for k in sm["pmc"]["FETCH_SIZE"] if f"conv3x3_wino4_kernel<{v}, 0>" in k] for v in ("false", "true")}
 assert keys["false"] and keys["true"], "the body conv launches (conv3x3_wino4_kernel<false> = ReLU, <true> = residual) are not in the PMC pass"
 px, wbytes = 16 * 64 * 256 * 256 * 4, 36 * 64 * 64 * 4      # one feature map; the pre-transformed weights (36 points)
 alg = {"false": 2 * px + wbytes, "true": 3 * px + wbytes}   # ReLU launches read x, write out; residual launches also read the skip tensor
