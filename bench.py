@@ -249,7 +249,10 @@ class DegradeSRWorkload:
                "algorithmic_flops_per_launch": self.body_flops_per_launch,
                "algorithmic_tflops": round(algorithmic, 2),
                "algorithmic_over_peak": round(algorithmic / F32_MFMA_PEAK_TFLOPS, 4),
-               "kernel_ms": round(kernel_ms, 4), "kernel_ms_mean_over_steps": round(kernel_ms_mean, 4), "launches_timed": len(ms) * n_body}
+               "kernel_ms": round(kernel_ms, 4), "kernel_ms_mean_over_steps": round(kernel_ms_mean, 4), "launches_timed": len(ms) * n_body,
+               "note": "frac is matrix-pipe utilisation of the FLOPs this kernel issues.  The F(4x4,3x3) kernel issues 1.78x fewer MFMA FLOPs for the "
+                       "same convolution than round 2's F(2x2,3x3) kernel (0.3775 ms per launch at frac 0.576 in BENCH_r02): compare kernel_ms / "
+                       "algorithmic_tflops across rounds, not frac" if self.body_algo == "winograd4" else None}
         out.update(traffic)
         return out
 

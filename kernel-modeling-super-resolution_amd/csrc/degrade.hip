@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) degrade_generic_kernel(DegradeParams p) {
         const int krow = p.kidx ? p.kidx[n] : (p.n_kernels == 1 ? 0 : n);
         const float* tp = p.taps + (size_t)(krow * p.C + c) * p.TY * p.TXP;
         const float* img = p.hr + n * p.sN + c * p.sC;
-        float acc = 0.f;
+        float acc = 0.f, acc_odd = 0.f;   // taps at even / odd column index b: the row-streaming kernel's two partial sums (v_pk_fma_f32 pairs)
         // odd row chunks accumulate tap rows bottom-up (see degrade_rowstream_kernel): keeps the two kernels bit-identical
         const bool up = ((i / p.rows_per_chunk) & 1) != 0;
         for (int al = 0; al < p.TY; ++al) {
@@ -125,9 +125,11 @@ __global__ void __launch_bounds__(256) degrade_generic_kernel(DegradeParams p) {
                 } else {
                     x = min(max(x, 0), p.W - 1);
                 }
-                acc = fmaf(tp[a * p.TXP + b], row[x], acc);
+                if (b & 1) acc_odd = fmaf(tp[a * p.TXP + b], row[x], acc_odd);
+                else acc = fmaf(tp[a * p.TXP + b], row[x], acc);
             }
         }
+        acc += acc_odd;
         if (p.noise_mode == KMSR_NOISE_GAUSSIAN) {
             float z[4];
             eps4(p.seed, p.offset, p.nz_base + (unsigned)n * p.nz_step + (unsigned)c, (unsigned)(i >> 2), (unsigned)j, z);
@@ -260,11 +262,14 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
                 if (outside[t]) *reinterpret_cast<f32x4*>(ring + r * ROWF + 4 * (lane + kWave * t)) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    float acc[TYB][NX];
+    // accumulators as register PAIRS: .x collects the taps at even column index b, .y the odd ones (v_pk_fma_f32 does two taps per
+    // instruction -- the fold loop is VALU-issue bound: 13 x NX x ~3.25 open rows scalar FMAs per HR row before); out = .x + .y.
+    // degrade_generic_kernel keeps the same two partial sums, so the two kernels stay bit-identical.
+    f32x2 acc[TYB][NX];
 #pragma unroll
     for (int m = 0; m < TYB; ++m)
 #pragma unroll
-        for (int x = 0; x < NX; ++x) acc[m][x] = 0.f;
+        for (int x = 0; x < NX; ++x) acc[m][x] = f32x2{0.f, 0.f};
 
     float sig = 0.f;
     if (p.noise_mode == KMSR_NOISE_GAUSSIAN) sig = sigma[krow * p.C + c];
@@ -359,11 +364,19 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
                 const int il = gl - m;
                 if (al < TY && il >= 0 && il < nrows) {  // wave-uniform
                     const float* __restrict__ tp = taps + (up ? TY - 1 - al : al) * TXP;
+                    static_assert(OFF % 2 == 0, "window pairs (OFF + b, OFF + b + 1), b even, must be the aligned halves of the LDS reads");
 #pragma unroll
-                    for (int b = 0; b < TX; ++b) {
-                        const float kv = tp[b];
+                    for (int b = 0; b < TX; b += 2) {
+                        if (b + 1 < TX) {
+                            const f32x2 kv = f32x2{tp[b], tp[b + 1]};
 #pragma unroll
-                        for (int x = 0; x < NX; ++x) acc[m][x] = fmaf(kv, win[x][OFF + b], acc[m][x]);
+                            for (int x = 0; x < NX; ++x)
+                                acc[m][x] = __builtin_elementwise_fma(kv, f32x2{win[x][OFF + b], win[x][OFF + b + 1]}, acc[m][x]);
+                        } else {        // odd TX: the last tap (even index) joins the even partial sum; never multiply a padded zero tap
+                            const float kv = tp[b];     // with a pixel outside the window (0 x NaN)
+#pragma unroll
+                            for (int x = 0; x < NX; ++x) acc[m][x].x = fmaf(kv, win[x][OFF + b], acc[m][x].x);
+                        }
                     }
                 }
             }
@@ -385,7 +398,7 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
                 for (int x = 0; x < NX; ++x) {
                     const int xo = xs0 + lane + kWave * x;
                     if (xo < p.w) {
-                        float v = acc[TYB - 1][x];
+                        float v = acc[TYB - 1][x].x + acc[TYB - 1][x].y;
                         if (p.noise_mode == KMSR_NOISE_GAUSSIAN) v += sig * pick4(z[x], i & 3);
                         else if (p.noise_mode == KMSR_NOISE_POOL) v += npl[(long long)i * p.w + xo];
                         lr[((long long)plane * p.h + i) * p.w + xo] = v;
@@ -397,7 +410,7 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
 #pragma unroll
                 for (int x = 0; x < NX; ++x) acc[m][x] = acc[m - 1][x];
 #pragma unroll
-            for (int x = 0; x < NX; ++x) acc[0][x] = 0.f;
+            for (int x = 0; x < NX; ++x) acc[0][x] = f32x2{0.f, 0.f};
             q = 0;
             ++gl;
         }
