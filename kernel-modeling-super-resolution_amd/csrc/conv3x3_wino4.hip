@@ -238,13 +238,6 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     //      touching LDS *and* global memory and then drains vmcnt(0) / lgkmcnt(0) at the next counted dependency -- here the first
     //      MFMA that reads a loaded weight register, i.e. a full HBM round trip per step.)
     constexpr unsigned ROOB = 0x80000000u;
-    int rpk[QRINSTR];                                       // per DMA instruction: this lane's (channel << 16 | row << 8 | quad), -1 = plane padding
-#pragma unroll
-    for (int i = 0; i < QRINSTR; ++i) {
-        const int L = (QRINSTR * wv + i) * 64 + lane;
-        const int ch = L / QPLANE_Q, u = L - ch * QPLANE_Q, row = u / QRQ, q = u - row * QRQ;
-        rpk[i] = u < QRROWS * QRQ ? (ch << 16 | row << 8 | q) : -1;
-    }
     int gR = 0, cR = 0, itR = it0;                          // next raw request = stream step gR = step cR of item itR
     unsigned roff[QRINSTR];
     const float* xstep = xg;                                // first channel of the step to request next
@@ -255,13 +248,14 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
         const int ty0 = (tile / p.tiles_x) * (4 * QTR), tx0 = (tile % p.tiles_x) * (4 * QTC);
         xstep = xg + (long long)n * p.Cin * HW;
         ch_left = p.Cin;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                         // everything below is recomputed HERE, once per item (hoisted it would be spilled)
 #pragma unroll
         for (int i = 0; i < QRINSTR; ++i) {
-            int pk = rpk[i];
-            asm volatile("" : "+v"(pk));                     // recompute ch * HW etc. HERE, once per item (hoisted they would be spilled)
-            const int ch = pk >> 16, row = (pk >> 8) & 255, q = pk & 255;
+            const int L = (QRINSTR * wv + i) * 64 + ln;      // this lane's quad of DMA instruction i: channel L / 192, u = L % 192 (u >= 180: plane padding)
+            const int ch = L / QPLANE_Q, u = L - ch * QPLANE_Q, row = u / QRQ, q = u - row * QRQ;
             const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * q;
-            const bool ok = pk >= 0 && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+            const bool ok = u < QRROWS * QRQ && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
             roff[i] = ok ? (unsigned)(ch * (int)HW + gy * W + gx) * 4u : ROOB;
         }
     };
@@ -384,11 +378,15 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     float* cur_out = out;
     unsigned cur_nrec = 0;
     int cur_cg = 0, cur_item = it0;
-    unsigned vo_cur[4];                                      // byte offset of (this lane's first channel 2 hh * 16 + 4 kq, row y0 + a, column x0)
+    int cur_y0 = 0, cur_xt = 0;                              // first output row of this wave's tile row; first column of the item's 16 tiles
+    // Only scalars describe the item while its steps run: the per-lane store offsets are derived inside the epilogue.  (Held in
+    // VGPRs across the steps they were spilled to scratch, and every reload inside the epilogue was a vmcnt(0) wait on the stores
+    // and prefetches in flight.)
     auto set_item = [&](int item) {
         const int tile = item % p.tiles, rest = item / p.tiles;
         const int n = rest / p.cgs, cg = rest % p.cgs;
-        const int y0 = (tile / p.tiles_x) * (4 * QTR) + 4 * tg, x0 = (tile % p.tiles_x) * (4 * QTC) + 4 * t16;
+        cur_y0 = (tile / p.tiles_x) * (4 * QTR) + 4 * tg;
+        cur_xt = (tile % p.tiles_x) * (4 * QTC);
         cur_cg = cg;
         cur_item = item;
         if constexpr (MODE == W4_PS) {
@@ -397,17 +395,26 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
             const int ocs = p.Cout >> 2;
             cur_out = out + ((long long)n * ocs + cg * 16) * (4 * HW);
             cur_nrec = (unsigned)min(16, ocs - cg * 16) * 4u * HWb;
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-                vo_cur[a] = (x0 < W && y0 + a < H) ? (unsigned)((hh * 8 + kq) * 4 * (int)HW + 2 * (y0 + a) * (2 * W) + 2 * x0) * 4u : OOB;
         } else {
             const long long go = ((long long)n * p.Cout + cg * QCO) * HW;
             cur_res = res + go;
             cur_out = out + go;
             cur_nrec = (unsigned)min(QCO, p.Cout - cg * QCO) * HWb;
+        }
+    };
+    // byte offset of (this lane's first channel, row cur_y0 + a, column cur_xt + 4 t16) inside the item's descriptor, OOB when outside the image
+    auto lane_offsets = [&](unsigned (&vo)[4]) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                         // derived from the lane id HERE (nothing lane-shaped stays live across the steps)
+        const int t = ln & 15, k4 = ln >> 4;
+        const int x0 = cur_xt + 4 * t;
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-                vo_cur[a] = (x0 < W && y0 + a < H) ? (unsigned)((2 * hh * 16 + 4 * kq) * (int)HW + (y0 + a) * W + x0) * 4u : OOB;
+        for (int a = 0; a < 4; ++a) {
+            const int y = cur_y0 + a;
+            unsigned o;
+            if constexpr (MODE == W4_PS) o = (unsigned)((hh * 8 + k4) * 4 * (int)HW + 2 * y * (2 * W) + 2 * x0) * 4u;
+            else o = (unsigned)((2 * hh * 16 + 4 * k4) * (int)HW + y * W + x0) * 4u;
+            vo[a] = (x0 < W && y < H) ? o : OOB;
         }
     };
     auto koff = [&](int k) { return (unsigned)((k >> 2) * 16 + (k & 3)) * HWb; };      // sub-block k = cbi * 4 + r: channel offset inside the lane's 32
@@ -481,6 +488,8 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     };
     auto epilogue = [&]() {
         const auto ro = __builtin_amdgcn_make_buffer_rsrc(cur_out, 0, cur_nrec, 0x00020000);
+        unsigned vo_cur[4];
+        lane_offsets(vo_cur);
         if constexpr (MODE == W4_PS) {
             // sub-block pairs (r = 2 dy, 2 dy + 1) of a channel block are the two interleaved columns of HR row 2 (y0 + a) + dy:
             // 8 consecutive floats = two 16-byte stores per (a, dy)
@@ -539,8 +548,10 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
             // per-channel sums of what this wave just stored (the bias gradient of the layer that consumes this tensor as its output
             // gradient): 16 tiles reduced in the DPP row, two float4 per (item, tile row, 4-channel group); fixed order -> run-to-run identical
             if constexpr (MODE == W4_TRAIN) {
-                if (csum && t16 == 15) {                      // csum: block-uniform
-                    float* o = csum + ((long long)cur_item * QTR + tg) * QCO + 2 * hh * 16 + 4 * kq;
+                int ln = lane;
+                asm volatile("" : "+v"(ln));                 // address from the lane id here (a lane-shaped pointer held across the steps gets spilled)
+                if (csum && (ln & 15) == 15) {                // csum: block-uniform
+                    float* o = csum + ((long long)cur_item * QTR + tg) * QCO + 2 * hh * 16 + 4 * (ln >> 4);
                     *reinterpret_cast<f32x4*>(o) = f32x4{cs[0], cs[1], cs[2], cs[3]};
                     *reinterpret_cast<f32x4*>(o + 16) = f32x4{cs[4], cs[5], cs[6], cs[7]};
                 }

@@ -1,23 +1,27 @@
 #!/usr/bin/env python3
-"""Diagnostic only: conv3x3_wino4.hip with s_memtime stamps at three points per step (before the step's wait + barrier, after the
-barrier, at the end of the step) and around the epilogue; per-wave sums land in a __device__ array read back by kmsr_diag_w4.
-Builds tools/diag/libkmsr_w4_stamped.so (load with KMSR_LIB_OVERRIDE; run tools/diag/stamp_w4.py)."""
+"""Diagnostic only: conv3x3_wino4.hip with s_memtime stamps inside the step (9 phases) and around the epilogue; per-wave sums land in a
+__device__ array read back by kmsr_diag_w4.  Builds tools/diag/libkmsr_w4_stamped.so (load with KMSR_LIB_OVERRIDE; run tools/diag/stamp_w4.py).
+Each stamp waits for lgkmcnt(0) (s_memtime returns through the scalar cache), so LDS latencies are charged to the phase that ends at the stamp."""
 import os, subprocess
 R = "/root/repo/kernel-modeling-super-resolution_amd/csrc"
 s = open(f"{R}/conv3x3_wino4.hip").read()
-def rep(a, b):
+def rep(a, b, count=1):
     global s
     assert a in s, a[:70]
-    s = s.replace(a, b, 1)
-rep("struct Wino4Params {", "__device__ unsigned long long g_w4_diag[256 * 4 * 8];\nstruct Wino4Params {")
-rep("    f32x4 acc[2][QPTS];", "    unsigned long long d_bar = 0, d_step = 0, d_epi = 0, d_first = 0, d_t0 = __builtin_readcyclecounter();\n    f32x4 acc[2][QPTS];")
-rep("        q_wait_vm<2 * QGROUPS * 2 + QRINSTR>();\n        q_barrier_lds();",
-    "        const unsigned long long T0 = __builtin_readcyclecounter();\n        q_wait_vm<2 * QGROUPS * 2 + QRINSTR>();\n        q_barrier_lds();\n        const unsigned long long T1 = __builtin_readcyclecounter();\n        d_bar += T1 - T0;")
-rep("        advance_a();\n    };", "        advance_a();\n        const unsigned long long T2 = __builtin_readcyclecounter();\n        if (FIRST) d_first += T2 - T1; else d_step += T2 - T1;\n    };")
+    s = s.replace(a, b, count)
+NPH = 9
+rep("namespace kmsr {\nnamespace {\n", "namespace kmsr {\n__device__ unsigned long long g_w4_diag[256 * 4 * 16];\nnamespace {\n")
+rep("    f32x4 acc[2][QPTS];", "    unsigned long long d_ph[%d] = {}, d_epi = 0, d_t0 = __builtin_readcyclecounter(), d_last = 0;\n    f32x4 acc[2][QPTS];" % NPH)
+ST = lambda i: "{ const unsigned long long T_ = __builtin_readcyclecounter(); d_ph[%d] += T_ - d_last; d_last = T_; }" % i
+rep("        q_wait_vm<2 * QGROUPS * 2 + QRINSTR>();\n        q_barrier_lds();", "        d_last = __builtin_readcyclecounter();\n        q_wait_vm<2 * QGROUPS * 2 + QRINSTR>();\n        q_barrier_lds();\n        " + ST(0))
+rep("        const Patch P = load_patch();\n        TPairs t;\n        Q_SB();", "        const Patch P = load_patch();\n        TPairs t;\n        Q_SB();\n        " + ST(1) + " Q_SB();")
+rep("        cols_pass(P, t);                                     // 36 packed VALU\n        Q_SB();", ST(2) + " Q_SB();\n        cols_pass(P, t);\n        Q_SB();\n        " + ST(3) + " Q_SB();")
+rep("        rows_pass(t, 0, 3, vn);                              // 21 packed VALU\n        Q_SB();", ST(4) + " Q_SB();\n        rows_pass(t, 0, 3, vn);\n        Q_SB();\n        " + ST(5) + " Q_SB();")
+rep("        rows_pass(t, 3, 6, vn);                              // 21 packed VALU (points 18 .. 35: every MFMA of this step has issued)\n        Q_SB();\n        advance_a();",
+    ST(6) + " Q_SB();\n        rows_pass(t, 3, 6, vn);\n        Q_SB();\n        " + ST(7) + "\n        advance_a();\n        " + ST(8))
 rep("        epilogue();\n", "        { const unsigned long long E0 = __builtin_readcyclecounter(); epilogue(); d_epi += __builtin_readcyclecounter() - E0; }\n")
-rep("#undef Q_MFMA8\n}", "    if (lane == 0) { unsigned long long* o = g_w4_diag + (blockIdx.x * 4 + wv) * 8; o[0] = d_bar; o[1] = d_step; o[2] = d_epi; o[3] = d_first; o[4] = __builtin_readcyclecounter() - d_t0; o[5] = n_my; }\n#undef Q_MFMA8\n}")
-s += '\nextern "C" int kmsr_diag_w4(unsigned long long* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(kmsr::g_w4_diag), sizeof(unsigned long long) * 256 * 4 * 8); }\n'
-s = s.replace("namespace kmsr {\nnamespace {\n", "namespace kmsr {\n__device__ unsigned long long g_w4_diag[256 * 4 * 8];\nnamespace {\n", 1).replace("__device__ unsigned long long g_w4_diag[256 * 4 * 8];\nstruct Wino4Params {", "struct Wino4Params {", 1)
+rep("#undef Q_MFMA8\n}", "    if (lane == 0) { unsigned long long* o = g_w4_diag + (blockIdx.x * 4 + wv) * 16; for (int i = 0; i < %d; ++i) o[i] = d_ph[i]; o[9] = d_epi; o[10] = __builtin_readcyclecounter() - d_t0; o[11] = n_my; }\n#undef Q_MFMA8\n}" % NPH)
+s += '\nextern "C" int kmsr_diag_w4(unsigned long long* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(kmsr::g_w4_diag), sizeof(unsigned long long) * 256 * 4 * 16); }\n'
 d = "/tmp/diag_w4_stamped"
 os.makedirs(d, exist_ok=True)
 open(f"{d}/conv3x3_wino4.hip", "w").write(s)

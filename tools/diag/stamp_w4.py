@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run the stamped F(4x4,3x3) build (KMSR_LIB_OVERRIDE=tools/diag/libkmsr_w4_stamped.so) on the body layer and print per-wave cycle sums."""
+"""Run the stamped F(4x4,3x3) build (KMSR_LIB_OVERRIDE=tools/diag/libkmsr_w4_stamped.so) on the body layer and print per-phase cycle sums."""
 import ctypes, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from kmsr_amd import _lib as L
@@ -13,15 +13,17 @@ for _ in range(30):
     conv3x3(x, pw, 64, bias=b, out=out, algo="winograd4", **kw)
 torch.cuda.synchronize()
 lib = L.load()
-buf = (ctypes.c_ulonglong * (256 * 4 * 8))()
+buf = (ctypes.c_ulonglong * (256 * 4 * 16))()
 lib.kmsr_diag_w4.argtypes = [ctypes.c_void_p]
 assert lib.kmsr_diag_w4(buf) == 0
-a = np.array(buf[:], dtype=np.float64).reshape(256, 4, 8)
-items = a[..., 5]
-print("mode", mode, "items per workgroup", items.min(), items.max())
-for i, nm in enumerate(["wait+barrier", "steps (not first)", "epilogues", "first steps", "kernel body total"]):
-    v = a[..., i]
-    print(f"{nm:20s} median {np.median(v):10.0f}  min {v.min():10.0f}  max {v.max():10.0f} cycles per wave")
-tot = np.median(a[..., 4]); n = np.median(items)
-print(f"per step: barrier {np.median(a[...,0])/(16*n):.0f}, step body {np.median(a[...,1])/(15*n):.0f}, first-step body {np.median(a[...,3])/n:.0f}; per item epilogue {np.median(a[...,2])/n:.0f}; "
-      f"MFMA floor per step 2304; sum/total = {(np.median(a[...,0])+np.median(a[...,1])+np.median(a[...,2])+np.median(a[...,3]))/tot:.3f}")
+a = np.array(buf[:], dtype=np.float64).reshape(256, 4, 16)
+n = np.median(a[..., 11]); steps = 16 * n
+names = ["wait + barrier", "raw DMA issue + patch reads issued", "MFMA groups 0-1 (+4 A loads)", "column pass (36 pk VALU; waits for the patch)", "MFMA groups 2-4 (+6 A loads)",
+         "row pass 0-2 (21 pk)", "MFMA groups 5-8 (+8 A loads)", "row pass 3-5 (21 pk)", "cursor advance / loop"]
+print("mode", mode, "items per workgroup", n)
+tot = 0
+for i, nm in enumerate(names):
+    v = np.median(a[..., i]) / steps; tot += v
+    print(f"  {nm:48s} {v:7.0f} cycles per step")
+print(f"  {'sum':48s} {tot:7.0f}   (MFMA floor 2304 = 576 + 864 + 1152 - ...: groups 0-1 512, 2-4 768, 5-8 1024)")
+print(f"  epilogue per item {np.median(a[..., 9]) / n:7.0f}; kernel body total per wave {np.median(a[..., 10]):9.0f} cycles")
