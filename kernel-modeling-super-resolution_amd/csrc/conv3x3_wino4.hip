@@ -210,24 +210,32 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     int gN = 0, cA = 0, itA = it0;                           // a_nxt = stream step gN = step cA of item itA
     auto a_item = [&](int it) { return p.cgs == 1 ? 0u : (unsigned)(((it / p.tiles) % p.cgs) * S) * (unsigned)(QUF * 4); };
     unsigned a_cur = a_item(it0), a_nxt = a_cur;
-    auto advance_a = [&]() {                                // a_cur <- a_nxt <- the step after it (past the end of the stream: stays)
-        a_cur = a_nxt;
+    unsigned a_nn = a_cur;                                  // the step after a_nxt (computed early in a step, taken over at its end)
+    auto a_lookahead = [&]() {                              // a_nn <- the step after a_nxt (past the end of the stream: stays)
+        a_nn = a_nxt;
         if (gN + 1 < T) {
             ++gN;
             if (++cA == S) {
                 cA = 0;
                 itA += istep;
-                a_nxt = a_item(itA);
+                a_nn = a_item(itA);
             } else {
-                a_nxt += (unsigned)(QUF * 4);
+                a_nn = a_nxt + (unsigned)(QUF * 4);
             }
         }
     };
+    auto advance_a = [&]() {                                // prologue form: a_cur <- a_nxt <- the step after it
+        a_lookahead();
+        a_cur = a_nxt;
+        a_nxt = a_nn;
+    };
     f32x4 A[QNA][2];
-    auto load_a = [&](unsigned step_off, int g) {           // group g of the step at step_off -> slot g % QNA
-#pragma unroll
-        for (int cbi = 0; cbi < 2; ++cbi)
-            A[g % QNA][cbi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, a_lane, step_off + (unsigned)((g * 2 + cbi) * 1024), 0));
+    auto load_a1 = [&](unsigned step_off, int g, int cbi) {  // group g, channel block cbi of the step at step_off -> slot g % QNA
+        A[g % QNA][cbi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, a_lane, step_off + (unsigned)((g * 2 + cbi) * 1024), 0));
+    };
+    auto load_a = [&](unsigned step_off, int g) {
+        load_a1(step_off, g, 0);
+        load_a1(step_off, g, 1);
     };
 
     // ---- raw rows: step gR = step cR of item itR.  Lane-linear quads: L = (3 wv + i) * 64 + lane <-> (channel = L / 192,
@@ -260,25 +268,45 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
         }
     };
     raw_map();
-    auto issue_raw = [&]() {
+    unsigned rec_cur = (unsigned)p.Cin * HWb;                // records of the next request's descriptor = max(ch_left, 0) planes
+    auto issue_dma1 = [&](int i) {                          // DMA instruction i of the request (same descriptor as issue_dma)
+        const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xstep), 0, rec_cur, 0x00020000);
+        float* rb = lds + QOFF_R + wr_off;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t*)(rb + (QRINSTR * wv + i) * 256), 16, roff[i], 0, 0, 0);
+    };
+    auto issue_dma = [&]() {
         // one descriptor per (image, step): base = the step's first channel, records = the channels that are left (raw-buffer range
         // checks cover the VGPR offset only, not soffset -- so the channel position lives in the base).  Past the end of the stream:
         // an empty descriptor (every lane out of range -> zeros; that slot is never multiplied).
-        const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xstep), 0, (unsigned)max(ch_left, 0) * HWb, 0x00020000);
+        const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xstep), 0, rec_cur, 0x00020000);
         float* rb = lds + QOFF_R + wr_off;
 #pragma unroll
         for (int i = 0; i < QRINSTR; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t*)(rb + (QRINSTR * wv + i) * 256), 16, roff[i], 0, 0, 0);
-        wr_off = wr_off == (QNRAW - 1) * QRAWF ? 0 : wr_off + QRAWF;
+    };
+    // the request cursor moves on in three pieces (inside a step they sit in the shadow of MFMAs; scalar instructions issued between
+    // two MFMAs of the same wave cost ~1 cycle each there, ~8 in a cluster of their own: tools/ubench/mfma_salu.hip)
+    auto raw_next_a = [&]() {
         xstep += (long long)QCK * HW;
         ch_left -= QCK;
         ++gR;
+    };
+    auto raw_next_b = [&]() {
         if (++cR == S) {
             cR = 0;
             itR += istep;
             if (gR < T) raw_map();
             else ch_left = 0;
         }
+    };
+    auto raw_next_c = [&]() { rec_cur = (unsigned)max(ch_left, 0) * HWb; };
+    auto ring_next = [&](int off) { return off == (QNRAW - 1) * QRAWF ? 0 : off + QRAWF; };
+    auto issue_raw = [&]() {                                // prologue form
+        issue_dma();
+        wr_off = ring_next(wr_off);
+        raw_next_a();
+        raw_next_b();
+        raw_next_c();
     };
 
     // ---- patch of lane (tile t16, channel kq) in step g: raw rows 4 tg + r (r = 0..5), raw columns 4 t16 + 3 + j (j = 0..5):
@@ -288,7 +316,6 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     int rd_off = 0;                                         // ring slot (float offset) of the patch to read next: raw(0), raw(1), ...
     auto load_patch = [&]() {
         const float* rp = lds + QOFF_R + rd_off + pbase;
-        rd_off = rd_off == (QNRAW - 1) * QRAWF ? 0 : rd_off + QRAWF;
         Patch P;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
@@ -296,6 +323,12 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
             P.e[r] = f32x2{rp[r * QRCOLS], rp[r * QRCOLS + 5]};
         }
         return P;
+    };
+    auto read_patch = [&](Patch& P, int k) {                // LDS read k of the 12 (one per MFMA pair inside a step: four waves posting
+        const float* rp = lds + QOFF_R + rd_off + pbase;    // all 12 right behind the barrier keep the LDS pipe -- and, in order
+        const int r = k >> 1;                               // behind it, every wave's first MFMAs -- busy for ~300 cycles)
+        if (k & 1) P.e[r] = f32x2{rp[r * QRCOLS], rp[r * QRCOLS + 5]};
+        else P.mid[r] = *reinterpret_cast<const f32x4*>(rp + r * QRCOLS + 1);
     };
     // V = B^T d B.  Column pass (T = B^T d) on the column PAIRS (0,5), (1,2), (3,4) -- the ds_read2_b32 result and the two halves of
     // the ds_read_b128 quad are already register pairs: 3 x 12 packed VALU.  Row pass (V[i][:] = T[i][:] B) inside each row on the
@@ -346,6 +379,7 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     float vv[QPTS];                                          // V of the step being multiplied; overwritten in place by the next step's V
     {                                                        // (rows 0-2 once the MFMAs of points 0 .. 19 have issued, rows 3-5 after the last group)
         const Patch P = load_patch();
+        rd_off = ring_next(rd_off);
         TPairs t;
         cols_pass(P, t);
         rows_pass(t, 0, 6, vv);
@@ -357,8 +391,9 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     // AGPRs and would copy the surplus tiles in and out of a[0:3] around each use.  The QVG first groups (transform points 0 .. 4 QVG - 1)
     // therefore accumulate in ArchVGPRs through the VGPR form of the instruction (inline asm); they are the first MFMAs of every step, so
     // >= 56 other MFMAs lie between their last write and the epilogue's VALU reads (no MFMA-result hazard to pad by hand).
-#define Q_MFMA8(G, VC, FIRST)                                                                                             \
-    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                    \
+#define Q_MFMA2(G, JJ, VC, FIRST)                                                                                         \
+    {                                                                                                                     \
+        constexpr int jj = (JJ);                                                                                          \
         _Pragma("unroll") for (int cbi = 0; cbi < 2; ++cbi) {                                                             \
             if constexpr ((G) < QVG) {                                                                                    \
                 if (FIRST)                                                                                                \
@@ -429,26 +464,58 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
         // (+ an item's stores / skip-tensor requests, which only makes the count conservative)
         q_wait_vm<2 * QGROUPS * 2 + QRINSTR>();
         q_barrier_lds();                                     // raw(g+1) visible to every wave; raw(g)'s slot free
-        issue_raw();                                         // raw(g+3)
-        const Patch P = load_patch();
+        Patch P;
         TPairs t;
         Q_SB();
-        Q_MFMA8(0, vc, FIRST); Q_SB(); load_a(a_cur, 5); Q_SB();
-        Q_MFMA8(1, vc, FIRST); Q_SB(); load_a(a_cur, 6); Q_SB();
+        // 36 MFMA pairs (one transform point, both channel blocks).  Everything else of the step sits BETWEEN pairs, one or two
+        // instructions at a time, where the matrix pipe is busy anyway: the raw request raw(g+3) (3 DMA), the 12 LDS reads of the
+        // next patch, the 18 A requests, and the scalar bookkeeping of the two cursors.
+#define Q_P(G, JJ) Q_MFMA2(G, JJ, vc, FIRST); Q_SB()
+        Q_P(0, 0); issue_dma1(0); read_patch(P, 0); Q_SB();
+        Q_P(0, 1); issue_dma1(1); read_patch(P, 1); Q_SB();
+        Q_P(0, 2); issue_dma1(2); read_patch(P, 2); Q_SB();
+        Q_P(0, 3); load_a1(a_cur, 5, 0); read_patch(P, 3); Q_SB();
+        Q_P(1, 0); load_a1(a_cur, 5, 1); read_patch(P, 4); Q_SB();
+        Q_P(1, 1); raw_next_a(); read_patch(P, 5); Q_SB();
+        Q_P(1, 2); read_patch(P, 6); Q_SB();
+        Q_P(1, 3); load_a1(a_cur, 6, 0); read_patch(P, 7); Q_SB();
+        Q_P(2, 0); load_a1(a_cur, 6, 1); read_patch(P, 8); Q_SB();
+        Q_P(2, 1); read_patch(P, 9); Q_SB();
+        Q_P(2, 2); read_patch(P, 10); Q_SB();
+        Q_P(2, 3); load_a1(a_cur, 7, 0); read_patch(P, 11); Q_SB();
+        Q_P(3, 0); load_a1(a_cur, 7, 1); Q_SB();
+        Q_P(3, 1); wr_off = rd_off; rd_off = ring_next(rd_off); Q_SB();
+        Q_P(3, 2); raw_next_b(); Q_SB();
+        Q_P(3, 3); load_a1(a_cur, 8, 0); load_a1(a_cur, 8, 1); Q_SB();
         cols_pass(P, t);                                     // 36 packed VALU
         Q_SB();
-        Q_MFMA8(2, vc, FIRST); Q_SB(); load_a(a_cur, 7); Q_SB();
-        Q_MFMA8(3, vc, FIRST); Q_SB(); load_a(a_cur, 8); Q_SB();
-        Q_MFMA8(4, vc, FIRST); Q_SB(); load_a(a_nxt, 4); Q_SB();
+        Q_P(4, 0); raw_next_c(); Q_SB();
+        Q_P(4, 1); a_lookahead(); Q_SB();
+        Q_P(4, 2);
+        Q_P(4, 3); load_a1(a_nxt, 4, 0); load_a1(a_nxt, 4, 1); Q_SB();
         rows_pass(t, 0, 3, vn);                              // 21 packed VALU
         Q_SB();
-        Q_MFMA8(5, vc, FIRST); Q_SB(); load_a(a_nxt, 0); Q_SB();
-        Q_MFMA8(6, vc, FIRST); Q_SB(); load_a(a_nxt, 1); Q_SB();
-        Q_MFMA8(7, vc, FIRST); Q_SB(); load_a(a_nxt, 2); Q_SB();
-        Q_MFMA8(8, vc, FIRST); Q_SB(); load_a(a_nxt, 3); Q_SB();
+        Q_P(5, 0);
+        Q_P(5, 1);
+        Q_P(5, 2);
+        Q_P(5, 3); load_a1(a_nxt, 0, 0); Q_SB();
+        Q_P(6, 0); load_a1(a_nxt, 0, 1); Q_SB();
+        Q_P(6, 1);
+        Q_P(6, 2);
+        Q_P(6, 3); load_a1(a_nxt, 1, 0); Q_SB();
+        Q_P(7, 0); load_a1(a_nxt, 1, 1); Q_SB();
+        Q_P(7, 1);
+        Q_P(7, 2);
+        Q_P(7, 3); load_a1(a_nxt, 2, 0); Q_SB();
+        Q_P(8, 0); load_a1(a_nxt, 2, 1); Q_SB();
+        Q_P(8, 1);
+        Q_P(8, 2);
+        Q_P(8, 3); load_a1(a_nxt, 3, 0); load_a1(a_nxt, 3, 1); Q_SB();
+#undef Q_P
         rows_pass(t, 3, 6, vn);                              // 21 packed VALU (points 18 .. 35: every MFMA of this step has issued)
         Q_SB();
-        advance_a();
+        a_cur = a_nxt;
+        a_nxt = a_nn;
     };
 
     // ---- epilogue of one item: lane-local output transform (A^T M A on register pairs), bias / ReLU / skip.  Sub-block k = cbi * 4 + r
@@ -568,7 +635,7 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
         item += istep;
         if (m + 1 < n_my) set_item(item);
     }
-#undef Q_MFMA8
+#undef Q_MFMA2
 }
 #undef Q_SB
 #undef Q_FENCE
