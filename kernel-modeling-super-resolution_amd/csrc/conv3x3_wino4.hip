@@ -575,12 +575,17 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
             }
         } else {
             const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cur_res), 0, cur_nrec, 0x00020000);
+            // Output stores and skip-tensor loads carry the non-temporal hint (aux = 2): both streams are touched once per launch, and as
+            // plain accesses the 33 MB store burst of all 256 workgroups' simultaneous epilogues (4.2 MB per XCD against a 4 MB L2)
+            // took ~3 us to be acknowledged -- time every wave then sat out at its first wait on a younger load (one in-order vmcnt).
+            // Measured on the body layer: ReLU form 225 -> 207 us, skip form 256 -> 246 us.  (The raw-row DMA stays temporal: halo
+            // rows are re-read by the neighbouring tiles from L2.)
             f32x4 rr[3][4];                                  // skip-tensor rows are requested two sub-blocks ahead
             auto fetch = [&](int k) {
                 if constexpr (HAS_RES) {
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
-                        rr[k % 3][a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo_cur[a] + koff(k), 0, 0));
+                        rr[k % 3][a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo_cur[a] + koff(k), 0, 2));
                 }
             };
             fetch(0);
@@ -602,7 +607,7 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
                             Y[a] += rr[k % 3][a];
                         }
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[a]), ro, vo_cur[a] + koff(k), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[a]), ro, vo_cur[a] + koff(k), 0, 2);
                     if constexpr (MODE == W4_TRAIN) {
                         if (vo_cur[a] != OOB) ssum += (Y[a].x + Y[a].y) + (Y[a].z + Y[a].w);
                     }

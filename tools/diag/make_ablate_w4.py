@@ -18,16 +18,24 @@ def build(name, edits):
     objs = " ".join(f"{R}/{o[:-4]}.o" for o in sorted(os.listdir(R)) if o.endswith(".hip") and o != "conv3x3_wino4.hip")
     subprocess.check_call(f"/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 {objs} {d}/conv3x3_wino4.o -o /root/repo/tools/diag/libkmsr_abl_w4_{name}.so", shell=True)
     print("built", name)
-NOA = [("        for (int cbi = 0; cbi < 2; ++cbi)\n            A[g % QNA][cbi] =", "        for (int cbi = 0; cbi < 2 && (gN == 0 || p.relu == 12345); ++cbi)\n            A[g % QNA][cbi] =")]
+import re
 NOBAR = [("        q_wait_vm<2 * QGROUPS * 2 + QRINSTR>();\n        q_barrier_lds();", "        q_wait_vm<2 * QGROUPS * 2 + QRINSTR>();")]
-NORAW = [("        issue_raw();                                         // raw(g+3)", "        if (p.relu == 12345) issue_raw();")]
+NORAW = [(f"issue_dma1({i}); read_patch", f"if (p.relu == 12345) issue_dma1({i}); read_patch") for i in range(3)]
 NOVALU = [("        cols_pass(P, t);                                     // 36 packed VALU", "        if (p.relu == 12345) cols_pass(P, t); else asm volatile(\"\" :: \"v\"(P.mid[0]), \"v\"(P.mid[5]), \"v\"(P.e[3]));"),
           ("        rows_pass(t, 0, 3, vn);                              // 21 packed VALU", "        if (p.relu == 12345) rows_pass(t, 0, 3, vn);"),
           ("        rows_pass(t, 3, 6, vn);                              // 21 packed VALU (points 18 .. 35: every MFMA of this step has issued)", "        if (p.relu == 12345) rows_pass(t, 3, 6, vn);")]
 NOEPI = [("        epilogue();\n", "        if (p.relu == 12345 || m + 1 == n_my) epilogue();\n")]
-NODRAIN = [("            if (have_prev && s_in_item < QSTG_SUB) drain(s_in_item);", "            if (p.relu == 12345 && have_prev && s_in_item < QSTG_SUB) drain(s_in_item);")]
+# cursors frozen inside the steps (every request repeats the first one of the workgroup: L2 hits -- compare with "rawl2")
+NOSALU = [("Q_P(1, 1); raw_next_a(); read_patch", "Q_P(1, 1); read_patch"), ("Q_P(3, 2); raw_next_b(); Q_SB();", "Q_P(3, 2);"),
+          ("Q_P(4, 0); raw_next_c(); Q_SB();", "Q_P(4, 0);"), ("Q_P(4, 1); a_lookahead(); Q_SB();", "Q_P(4, 1);")]
 RAWL2 = [("        xstep += (long long)QCK * HW;\n        ch_left -= QCK;", "        if (p.relu == 12345) { xstep += (long long)QCK * HW; ch_left -= QCK; }")]   # every raw request re-reads the same rows: L2 hits
-ABL = {"noa": NOA, "nobar": NOBAR, "noraw": NORAW, "novalu": NOVALU, "noepi": NOEPI, "nodrain": NODRAIN, "rawl2": RAWL2,
-       "mfmaonly": NOA + NOBAR + NORAW + NOVALU + NOEPI + NODRAIN, "noa_noraw": NOA + NORAW, "novalu_noepi": NOVALU + NOEPI}
+NOLDS = [(f"read_patch(P, {k}); Q_SB();", "Q_SB();") for k in range(12)] + [("        Patch P;\n        TPairs t;\n        Q_SB();", "        Patch P = {};\n        TPairs t;\n        Q_SB();")]
+NOSTORE = [("                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[a]), ro, vo_cur[a] + koff(k), 0, 0);",
+            "                    if (p.relu == 12345) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[a]), ro, vo_cur[a] + koff(k), 0, 0); else asm volatile(\"\" :: \"v\"(Y[a]));")]
+# stores of every item land on the workgroup's FIRST tile: L2-resident lines, no HBM write stream
+STOREL2 = [("        if (m + 1 < n_my) set_item(item);", "        if (m + 1 < n_my && p.relu == 12345) set_item(item);")]
+ABL = {"nostore": NOSTORE, "storel2": STOREL2, "nobar": NOBAR, "noraw": NORAW, "novalu": NOVALU, "noepi": NOEPI, "nosalu": NOSALU, "rawl2": RAWL2, "nolds_novalu": NOLDS + NOVALU,
+       "rawl2_noepi": RAWL2 + NOEPI, "novalu_noepi": NOVALU + NOEPI,
+       "mfmaonly": NOBAR + NORAW + NOVALU + NOEPI + NOSALU + NOLDS}
 for n in (sys.argv[1:] or ABL):
     build(n, ABL[n])

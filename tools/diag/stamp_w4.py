@@ -18,12 +18,12 @@ lib.kmsr_diag_w4.argtypes = [ctypes.c_void_p]
 assert lib.kmsr_diag_w4(buf) == 0
 a = np.array(buf[:], dtype=np.float64).reshape(256, 4, 16)
 n = np.median(a[..., 11]); steps = 16 * n
-names = ["wait + barrier", "raw DMA issue + patch reads issued", "MFMA groups 0-1 (+4 A loads)", "column pass (36 pk VALU; waits for the patch)", "MFMA groups 2-4 (+6 A loads)",
-         "row pass 0-2 (21 pk)", "MFMA groups 5-8 (+8 A loads)", "row pass 3-5 (21 pk)", "cursor advance / loop"]
+names = ["wait + barrier", "MFMA pairs 0-15 (+ raw request, 12 patch reads, 8 A loads, cursors)", "column pass (36 pk VALU; waits for the patch)", "MFMA pairs 16-19 (+2 A loads)",
+         "row pass 0-2 (21 pk)", "MFMA pairs 20-35 (+8 A loads)", "row pass 3-5 (21 pk)", "loop tail"]
 print("mode", mode, "items per workgroup", n)
 tot = 0
 for i, nm in enumerate(names):
     v = np.median(a[..., i]) / steps; tot += v
     print(f"  {nm:48s} {v:7.0f} cycles per step")
-print(f"  {'sum':48s} {tot:7.0f}   (MFMA floor 2304 = 576 + 864 + 1152 - ...: groups 0-1 512, 2-4 768, 5-8 1024)")
+print(f"  {'sum':48s} {tot:7.0f}   (MFMA floor 2304 = 1024 + 256 + 1024)")
 print(f"  epilogue per item {np.median(a[..., 9]) / n:7.0f}; kernel body total per wave {np.median(a[..., 10]):9.0f} cycles")
