@@ -578,7 +578,8 @@ class SRNet(nn.Module):
             h = self._conv(f"b{i}.2", blk.conv2, t, residual=h)
         h = self._conv("body_tail", self.body_tail, h, residual=f)
         if self.fuse_upsampler and len(self.up) == 2 and self.n_colors <= _FusedUpsampler.MAX_BANDS \
-                and min(h.shape[-2:]) >= _FusedUpsampler.MIN_SIZE:
+                and min(h.shape[-2:]) >= _FusedUpsampler.MIN_SIZE \
+                and h[0].numel() * 4 * min(h.shape[0], 64) < 2 ** 31:      # the frame launch's 32-bit offsets (kmsr_upsampler_frame_f32)
             return self._fused_up(self, h)
         for i, up in enumerate(self.up):
             h = self._conv(f"up{i}", up, h, pixel_shuffle=True)      # conv F->4F with PixelShuffle(2) fused into the store

@@ -34,7 +34,10 @@ NOSTORE = [("                    __builtin_amdgcn_raw_buffer_store_b128(__builti
             "                    if (p.relu == 12345) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[a]), ro, vo_cur[a] + koff(k), 0, 0); else asm volatile(\"\" :: \"v\"(Y[a]));")]
 # stores of every item land on the workgroup's FIRST tile: L2-resident lines, no HBM write stream
 STOREL2 = [("        if (m + 1 < n_my) set_item(item);", "        if (m + 1 < n_my && p.relu == 12345) set_item(item);")]
-ABL = {"nostore": NOSTORE, "storel2": STOREL2, "nobar": NOBAR, "noraw": NORAW, "novalu": NOVALU, "noepi": NOEPI, "nosalu": NOSALU, "rawl2": RAWL2, "nolds_novalu": NOLDS + NOVALU,
+# A operands frozen at the prologue's load (no A requests inside the steps)
+NOA = [("        A[g % QNA][cbi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, a_lane, step_off + (unsigned)((g * 2 + cbi) * 1024), 0));",
+        "        if (gN == 0 || p.relu == 12345) A[g % QNA][cbi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, a_lane, step_off + (unsigned)((g * 2 + cbi) * 1024), 0));")]
+ABL = {"noa": NOA, "nostore": NOSTORE, "storel2": STOREL2, "nobar": NOBAR, "noraw": NORAW, "novalu": NOVALU, "noepi": NOEPI, "nosalu": NOSALU, "rawl2": RAWL2, "nolds_novalu": NOLDS + NOVALU,
        "rawl2_noepi": RAWL2 + NOEPI, "novalu_noepi": NOVALU + NOEPI,
        "mfmaonly": NOBAR + NORAW + NOVALU + NOEPI + NOSALU + NOLDS}
 for n in (sys.argv[1:] or ABL):

@@ -39,5 +39,6 @@ out = {
                       for k, v in sm["pmc"]["FETCH_SIZE"].items()},
 }
 json.dump(out, open(f"{R}/profiles/{rnd}_bench_pmc_traffic.json", "w"), indent=1)
-shutil.copy(glob.glob(f"{R}/gpurun_out/{name}/trace/*/*_kernel_stats.csv")[0], f"{R}/profiles/{rnd}_bench_kernel_stats.csv")
+shutil.copy(max(glob.glob(f"{R}/gpurun_out/{name}/trace/*/*_kernel_stats.csv"), key=os.path.getmtime),   # gpurun MERGES into gpurun_out/: older boxes' directories stay
+            f"{R}/profiles/{rnd}_bench_kernel_stats.csv")
 print(f"traffic {out['traffic_bytes_per_launch'] / 1e6:.1f} MB per launch = {out['traffic_over_algorithmic']:.3f} x algorithmic; sha {out['kernel_source_sha256_16']}")
