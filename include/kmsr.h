@@ -336,7 +336,9 @@ int kmsr_conv5x5_ps4_fwd_bf16(int32_t N, int32_t Cin_p, int32_t H, int32_t W, in
  * interior 5x5 map into 8 border-class maps (0 top, 1 bottom, 2 left, 3 right -- corners excluded --, 4..7 the corners tl, tr,
  * bl, br).  wcls [8][Cin][25][16*bands] (tap = dy*5+dx, out channel = band*16 + 4a + b), bcls [8][16*bands]; for every border LR
  * pixel (i,j) of every image:  y[n, band, 4i+a, 4j+b] = bcls[c] + sum wcls[c][ci][dy][dx] * h[n, ci, i+dy-2, j+dx-2]  (zero
- * outside the image) is written into y [N,bands,4H,4W] (the interior launch's output).  H, W >= 4, 1..8 bands. */
+ * outside the image) is written into y [N,bands,4H,4W] (the interior launch's output).  H, W >= 4, 1..8 bands; bcls and y 16-byte
+ * aligned (KMSR_E_BADARG otherwise); min(N, 64) images of h below 2 GB (32-bit buffer offsets; KMSR_E_UNSUPPORTED otherwise --
+ * callers then run the three layers one by one).  Any W; W % 4 == 0 with a 16-byte aligned h takes the 16-byte patch-row loads. */
 int kmsr_upsampler_frame_f32(const float* h, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t bands, const float* wcls,
                              const float* bcls, float* y, void* stream);
 

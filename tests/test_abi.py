@@ -209,3 +209,7 @@ def test_no_wide_store_with_sgpr_soffset():
             assert "buffer_store_dword" in isa, f
             bad = pat.findall(isa)
             assert not bad, f"{f}: wide buffer store with an SGPR soffset: {bad[:2]}"
+            if f == "conv3x3_wino4.hip":
+                # round 3: a VGPR spilled across the F(4x4) kernel's steps is reloaded from scratch inside the epilogue, and every such
+                # reload is an s_waitcnt vmcnt(0) on the stores and prefetches in flight (8 us per launch); the kernel must stay spill-free
+                assert "scratch_" not in isa, "conv3x3_wino4.hip: VGPR spills to scratch (see DESIGN.md 4.4c)"
