@@ -90,6 +90,21 @@ def test_error_codes_and_messages_without_gpu():
     assert lib.kmsr_degrade_workspace_bytes(_desc(factor=4, down_mode=L.DOWN_STRIDE)) == 5 * 13 * 16 * 4
 
 
+def test_upsampler_frame_argument_checks_without_gpu():
+    """kmsr_upsampler_frame_f32 rejects what its MFMA kernel cannot address BEFORE any launch (fake pointers are never dereferenced):
+    misaligned class biases / output (16-byte accesses), and min(N, 64) input images beyond the 2 GB a workgroup's buffer descriptor spans
+    (SRNet then runs the upsampler layer by layer: sr.py gate)."""
+    lib = L.load()
+    p = lambda a: C.c_void_p(a)
+    call = lambda h, N, F, H, W, b, wc, bc, y: lib.kmsr_upsampler_frame_f32(p(h), N, F, H, W, b, p(wc), p(bc), p(y), None)
+    assert call(0, 1, 64, 16, 16, 3, 0x1000, 0x1000, 0x1000) == L.KMSR_E_BADARG            # null input
+    assert call(0x1000, 1, 64, 16, 16, 9, 0x1000, 0x1000, 0x1000) == L.KMSR_E_UNSUPPORTED   # 9 bands
+    assert call(0x1000, 1, 64, 16, 16, 3, 0x1000, 0x1004, 0x1000) == L.KMSR_E_BADARG        # class biases not 16-byte aligned
+    assert call(0x1000, 1, 64, 16, 16, 3, 0x1000, 0x1000, 0x1008) == L.KMSR_E_BADARG        # output not 16-byte aligned
+    assert call(0x1000, 64, 64, 512, 512, 3, 0x1000, 0x1000, 0x1000) == L.KMSR_E_UNSUPPORTED
+    assert b"2 GB" in lib.kmsr_last_error()
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
