@@ -427,6 +427,8 @@ def test_conv5x5_ps4_vs_torch(N, Cin, H, W, Cout, bias, gpu_device):
                                                         (3, 64, 1, (1, 3, 64, 64)), (7, 32, 1, (2, 7, 9, 12)),
                                                         # W % 4 != 0: the frame kernel's scalar patch loads; 5 images: a workgroup's 64 border pixels straddle images
                                                         (3, 32, 1, (5, 3, 11, 18)),
+                                                        # 40 features: K = 1000 is not a whole number of the frame kernel's 160-row chunks
+                                                        (3, 40, 1, (1, 3, 16, 16)),
                                                         # 9 bands: above the frame kernel's 8-band limit -> the default eval path
                                                         # must run layer by layer instead of raising (round-2 advisor finding)
                                                         (9, 32, 1, (1, 9, 12, 16))])
