@@ -39,7 +39,9 @@ NOA = [("        A[g % QNA][cbi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_ra
         "        if (gN == 0 || p.relu == 12345) A[g % QNA][cbi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, a_lane, step_off + (unsigned)((g * 2 + cbi) * 1024), 0));")]
 # the raw rows are still requested, but no step waits for them (reads whatever is in the ring)
 NORAWWAIT = [("        q_wait_vm<2 * QGROUPS * 2 + QRINSTR>();\n        q_barrier_lds();", "        q_barrier_lds();")]
-ABL = {"norawwait": NORAWWAIT, "noa": NOA, "nostore": NOSTORE, "storel2": STOREL2, "nobar": NOBAR, "noraw": NORAW, "novalu": NOVALU, "noepi": NOEPI, "nosalu": NOSALU, "rawl2": RAWL2, "nolds_novalu": NOLDS + NOVALU,
+# the skip tensor of every item is read from image 0 (16.8 MB: L2 / memory-side cache) instead of its own image
+RESL2 = [("            cur_res = res + go;", "            cur_res = res + (p.relu == 12345 ? go : (long long)cg * QCO * HW);")]
+ABL = {"resl2": RESL2, "norawwait": NORAWWAIT, "noa": NOA, "nostore": NOSTORE, "storel2": STOREL2, "nobar": NOBAR, "noraw": NORAW, "novalu": NOVALU, "noepi": NOEPI, "nosalu": NOSALU, "rawl2": RAWL2, "nolds_novalu": NOLDS + NOVALU,
        "rawl2_noepi": RAWL2 + NOEPI, "novalu_noepi": NOVALU + NOEPI,
        "mfmaonly": NOBAR + NORAW + NOVALU + NOEPI + NOSALU + NOLDS}
 for n in (sys.argv[1:] or ABL):
