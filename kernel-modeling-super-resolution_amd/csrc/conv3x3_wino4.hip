@@ -3,28 +3,33 @@
 // Why a second Winograd kernel.  conv3x3_wino_vreg.hip (F(2x2,3x3)) sits at 0.56-0.58 of the fp32 MFMA pipe and its remaining
 // overheads (transform VALU that cannot co-issue with the f32 MFMA, the LDS-DMA weight stream, the item hand-over) are structural
 // (DESIGN 4.4b).  F(4x4,3x3) needs 36 multiplies per 16 outputs and (ci, co) pair instead of 64: 1.78x fewer MFMAs for the same
-// convolution, and -- per output -- fewer transform instructions as well (144 + 100 VALU per 6x6 patch / 4x4 block instead of
-// 4 x (32 + 24)).  Arithmetic stays fp32 (v_mfma_f32_16x16x4_f32 is an exact fma chain); the transforms with the points
+// convolution, and -- per output -- fewer transform instructions as well (78 + 54 packed VALU per 6x6 patch / 4x4 block instead of
+// 4 x (32 + 24) scalar ones).  Arithmetic stays fp32 (v_mfma_f32_16x16x4_f32 is an exact fma chain); the transforms with the points
 // {0, +-1, +-2, inf} re-associate the sums: measured max error vs float64 5e-6 .. 8e-6 of the output scale for one 64 -> 64 layer
 // (F(2x2,3x3): 4e-7; tests hold 2e-5), 1.4e-6 through the 33-layer SR body (the skip connections carry the scale).
 //
 // Design (one persistent 4-wave workgroup per CU, ONE wave per SIMD with the whole 512-entry register file):
 //   * MFMA tile 16 channels x 16 tiles x 4 input channels.  A wave owns 32 output channels x 16 tiles (one tile row of 4x4 tiles =
-//     4 output rows x 64 columns) for ALL 36 transform points: 2 x 36 accumulator tiles x 4 registers = 288 registers
-//     (hipcc keeps them in the AGPR half).  Lane (tile t = lane & 15, channel kq = lane >> 4) supplies the B operand
+//     4 output rows x 64 columns) for ALL 36 transform points: 2 x 36 accumulator tiles x 4 registers = 288 registers -- more than
+//     the 256 AGPRs: the first QVG point groups accumulate in ArchVGPRs through the VGPR form of the instruction (inline asm), the
+//     other 224 registers sit in AGPRs.  Lane (tile t = lane & 15, channel kq = lane >> 4) supplies the B operand
 //     V[xi][4 s + kq][t] for every xi: exactly the 6x6 input transform B^T d B of ITS patch, which it computes itself (78 packed-fp32
 //     VALU per 72 MFMAs) from the raw rows in LDS.  The output transform A^T M A is lane-local too: no exchange, no epilogue barrier.
 //   * the workgroup = 2 channel halves x 2 tile rows = 64 channels x (8 rows x 64 columns) per item, PERSISTENT over an interleaved
-//     item list; the 4-channel steps of all its items form ONE stream.
+//     item list (skip-form launches walk it backwards: the next launch of a residual network starts on the lines stored last); the
+//     4-channel steps of all its items form ONE stream.
 //   * A operands (the pre-transformed weights U = G g G^T, 36 x 64 x 4 floats = 36 KB per step and workgroup) do NOT go through
-//     LDS: an LDS-DMA instruction costs ~60 cycles of the SIMD's MFMA time on gfx950 and a buffer_load + ds_write ~29
-//     (profiles/r02_ubench_dma_vs_reg.log); here every wave loads the 18 KB of ITS 32 channels per step with 18
-//     buffer_load_dwordx4 straight into the registers the MFMAs read (packed lane-linear: 1 KB per instruction), one whole step
-//     ahead (72 registers) -- the stream is the same 590 KB for every workgroup of a layer, i.e. L2 / L1 hits.
-//   * raw input rows (4 channels x 10 rows x 72 columns = 12 KB per step) arrive by LDS-DMA in a 3-slot ring, requested three
+//     LDS: every wave loads the 18 KB of ITS 32 channels per step with 18 buffer_load_dwordx4 straight into the registers the MFMAs
+//     read (packed lane-linear: 1 KB per instruction), 4 .. 9 groups ahead in a 5-slot register ring -- the stream is the same 590 KB
+//     for every workgroup of a layer, i.e. L2 / L1 hits.  (The LDS form -- LDS-DMA + ds_read_b128 -- was built and measured: no faster.)
+//   * raw input rows (4 channels x 10 rows x 72 columns = 12 KB per step) arrive by buffer LDS-DMA in a 3-slot ring, requested three
 //     steps ahead whatever item they belong to; padding (image border, channel tail, end of stream) is an out-of-range buffer
 //     offset, for which the hardware writes zeros: the transform has no masks and every wave issues the same 3 DMA instructions
 //     per step.  ONE barrier per step.
+//   * a step is written as 36 MFMA pairs with slots between them; the raw request, the 12 LDS reads of the next patch, the 18 A
+//     requests and the scalar bookkeeping of the cursors sit in those slots one or two instructions at a time (a scalar instruction
+//     between two MFMAs costs ~1 cycle, an LDS read 4-8, a 16-byte load 20-50: tools/ubench/mfma_salu.hip, mfma_store.hip).
+//     Nothing lane-shaped stays live across the steps: the kernel has no VGPR spills (tests/test_abi.py greps the ISA).
 //   * vmcnt retires in order: a step's 18 weight loads, 3 DMA instructions and an item's 32 stores (+ 32 skip-tensor loads) share
 //     one queue.  hipcc counts the register loads itself; the DMA is covered by an explicit counted wait before the barrier.
 // Requires W % 4 == 0 and 16-byte aligned x / packed_w / out / residual.
