@@ -341,9 +341,13 @@ class DegradeSRWorkload:
         deg["oracle_c_all_cores"] = round(rate(lambda: oracle.vb_blur_stride(hr, kern, 4), 1.0, 200)[0], 2)
         deg["torch_ops_all_cores"] = round(rate(lambda: vb_torch(hr_t, kern_t), 1.5, 200)[0], 2)
         threads(1)
-        t0 = time.perf_counter()
-        one()
-        v_one = 1.0 / (time.perf_counter() - t0)
+        one()                                         # warm-up (thread-pool resize, first-touch)
+        t_one = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            one()
+            t_one.append(time.perf_counter() - t0)
+        v_one = 1.0 / sorted(t_one)[1]                # median of 3 timed calls
         deg["oracle_c_1_thread"] = round(rate(lambda: oracle.vb_blur_stride(hr, kern, 4), 1.0, 200)[0], 2)
         deg["torch_ops_1_thread"] = round(rate(lambda: vb_torch(hr_t, kern_t), 1.5, 200)[0], 2)
         threads(cores)
@@ -365,7 +369,8 @@ class DegradeSRWorkload:
         return {"value": round(v_all, 3), "unit": "LR patches/s", "cores": cores, "kind": "port",
                 "sample": f"{n_all} patch(es): HR 3x1024x1024 -> LR 256^2 -> SR 1024^2, oracle C degradation + torch-CPU "
                           f"SRNetTorch fp32, {el_all:.1f} s on {cores} threads",
-                "one_thread": {"value": round(v_one, 4), "cores": 1, "sample": "1 patch, same step, OMP / ATen threads = 1"},
+                "one_thread": {"value": round(v_one, 4), "cores": 1, "sample": "median of 3 timed calls (1 warm-up) of the same 1-patch step, OMP / ATen threads = 1",
+                               "calls_s": [round(t, 3) for t in t_one]},
                 "degrade_only": deg,
                 "psnr_vs_oracle": deltas}
 
@@ -485,26 +490,42 @@ def secondary_lines(device, rank, world, kd, sync):
     live, after the headline's timed region, every leg bracketed like the headline (barrier + synchronize on both sides, MAX over
     ranks); a few steps each, <= ~5 s in total.  All ranks run them (config 3's gradient all-reduce is a collective)."""
     def bracket(fn, n):
+        """-> (ms per step over the bracketed region, MAX over ranks; this rank's per-step ms from HIP events on the launch
+        stream: one event in front of every step and one behind the last, no synchronisation inside the region)."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
         sync()
         kd.barrier()
         sync()
         t0 = time.perf_counter()
-        for _ in range(n):
+        for i in range(n):
+            ev[i].record()
             fn()
+        ev[n].record()
         sync()
         kd.barrier()
         sync()
-        return kd.max_over_ranks(time.perf_counter() - t0, device=device) / n * 1e3
+        ms = kd.max_over_ranks(time.perf_counter() - t0, device=device) / n * 1e3
+        return ms, sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))
+
+    def spread(per):
+        return {"min": round(per[0], 3), "median": round(per[len(per) // 2], 3), "max": round(per[-1], 3)}
 
     out = {}
     # ---- config 3: SR x4 training step, batch 32 per GPU, on-the-fly degradation, flat-bucket gradient all-reduce (RCCL at N > 1)
     wl = TrainWorkload(device, rank)
-    for _ in range(2):
-        wl.step()
-    ms = bracket(wl.step, 3)
+    wl.step()
+    # self-check of the N > 1 path (round-3 verdict): after the first step's flat-bucket all-reduce every rank must hold the SAME
+    # averaged gradient bit for bit, and the gather must have heard from `world` distinct ranks
+    ranks_seen, grads_equal = kd.ranks_agree(wl.bucket.flat)
+    if ranks_seen != world or not grads_equal:
+        raise RuntimeError(f"multi-rank self-check failed: {ranks_seen} of {world} ranks seen, averaged gradients identical: {grads_equal}")
+    wl.step()
+    ms, per = bracket(wl.step, 5)
     rf = wl.roofline(ms)
     out["train"] = {"config": f"configs[2]: {wl.name}, HR [{wl.B},{wl.C},{wl.H},{wl.W}] per GPU, fp32, Adam", "train_ms_per_step": round(ms, 3),
-                    "value": round(wl.B * world / (ms * 1e-3), 2), "unit": "LR patches/s (all ranks)", "steps_timed": 3,
+                    "value": round(wl.B * world / (ms * 1e-3), 2), "unit": "LR patches/s (all ranks)", "steps_timed": 5,
+                    "step_ms_rank0": spread(per),
+                    "rccl_ranks_seen": ranks_seen, "averaged_gradients_bit_identical_across_ranks": grads_equal,
                     "issued_mfma_tflops_per_gpu": rf["achieved"], "frac_of_f32_mfma_peak": rf["frac"],
                     "algorithmic_tflops_per_gpu": rf["algorithmic_tflops"],
                     "grad_allreduce": "none (1 rank)" if world == 1 else f"{wl.bucket.flat.numel() * 4} B fp32 in {len(wl.bucket._slices)} "
@@ -515,11 +536,12 @@ def secondary_lines(device, rank, world, kd, sync):
     wl = SRBf16Workload(device, rank)
     for _ in range(2):
         wl.step()
-    ms = bracket(wl.step, 3)
+    ms, per = bracket(wl.step, 5)
     rf = wl.roofline(ms)
     io_bytes = 4.0 * wl.C * wl.h * wl.w + 4.0 * wl.C * wl.H * wl.W            # fp32 LR tile in, fp32 SR tile out (module boundary)
     out["sr_bf16"] = {"config": f"configs[3]: {wl.name}, LR [1,{wl.C},{wl.h},{wl.w}] -> SR [1,{wl.C},{wl.H},{wl.W}]", "bf16_tile_ms": round(ms, 3),
-                      "value": round(wl.patches_per_step * world / (ms * 1e-3), 2), "unit": "256^2 LR patches/s (all ranks)", "tiles_timed": 3,
+                      "value": round(wl.patches_per_step * world / (ms * 1e-3), 2), "unit": "256^2 LR patches/s (all ranks)", "tiles_timed": 5,
+                      "tile_ms_rank0": spread(per),
                       "body_layer_ms": rf["kernel_ms"], "body_layer_frac_of_hbm": rf["frac"], "body_layer_GBps": rf["achieved"],
                       "tile_min_io_GBps": round(io_bytes / (ms * 1e-3) / 1e9, 1)}
     del wl
@@ -533,10 +555,10 @@ def secondary_lines(device, rank, world, kd, sync):
     def estimate():
         return gen.extract_effective_kernels(x, reduce_batch=False)
     estimate()
-    ms = bracket(estimate, 3)
+    ms, per = bracket(estimate, 5)
     out["kernelgan"] = {"config": "configs[4]: 512 x [5,256,256] patches, DynamicMultiBandLinearGenerator (ConditionEncoder + 6-layer chain "
                                   f"composition), {n_local} patches on this rank", "kernelgan_ms_per_512": round(ms, 3),
-                        "value": round(512 / (ms * 1e-3), 1), "unit": "patches/s (all ranks)", "passes_timed": 3,
+                        "value": round(512 / (ms * 1e-3), 1), "unit": "patches/s (all ranks)", "passes_timed": 5, "pass_ms_rank0": spread(per),
                         "encoder_flops_per_512": 512 * 2.0 * 9 * (5 * 32 * 256 * 256 + 32 * 64 * 128 * 128 + 64 * 64 * 64 * 64),
                         "encoder_frac_of_f32_mfma_peak": round(n_local * 2.0 * 9 * (5 * 32 * 256 * 256 + 32 * 64 * 128 * 128 + 64 * 64 * 64 * 64)
                                                                / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
@@ -571,21 +593,37 @@ def launch_ranks(n, argv):
     (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), relays rank 0's JSON line on
     its own stdout (everything else the ranks print goes to stderr) and exits non-zero when any rank failed.  Nothing is
     exec()ed: the ranks are ordinary child processes."""
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this pool
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
-    line_json = None
-    for line in proc.stdout:
-        if line.startswith("{") and '"metric"' in line:
-            line_json = line.rstrip("\n")
-        else:
-            sys.stderr.write(line)
-    rc = proc.wait()
+    for attempt in range(3):
+        with socket.socket() as sk:                        # bind-then-close: another process can take the port before the
+            sk.bind(("127.0.0.1", 0))                      # launcher's store binds it -> retry with a fresh one
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        line_json, rank_output = None, False
+        import threading
+        err_lines = []
+
+        def pump(pipe=proc.stderr, sink=err_lines):
+            for ln in pipe:
+                sink.append(ln)
+                sys.stderr.write(ln)
+        th = threading.Thread(target=pump, daemon=True)
+        th.start()
+        for line in proc.stdout:
+            rank_output = True
+            if line.startswith("{") and '"metric"' in line:
+                line_json = line.rstrip("\n")
+            else:
+                sys.stderr.write(line)
+        rc = proc.wait()
+        th.join(timeout=5)
+        port_lost = rc != 0 and not rank_output and any("EADDRINUSE" in ln or "address already in use" in ln.lower() for ln in err_lines)
+        if not port_lost:
+            break
+        sys.stderr.write(f"bench.py: port {port} was taken before the launcher bound it, retrying ({attempt + 1}/3)\n")
     if rc != 0:
         sys.stderr.write(f"bench.py: a rank of the {n}-rank job failed (launcher exit code {rc})\n")
         sys.exit(rc)
@@ -614,7 +652,8 @@ def main():
         launch_ranks(args.gpus, sys.argv[1:])          # before ANY GPU call in this process
         return
     if env_world is not None and int(env_world) != args.gpus:
-        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: the launcher's world size is used\n")
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}: refusing to report a line whose n_gpus "
+                 "is not the flag's value")
 
     from kmsr_amd import dist as kd
     # "nccl" is RCCL on ROCm; no group for a single process.  Rehearsal on a one-GPU box (several ranks sharing card 0,
@@ -646,6 +685,7 @@ def main():
           "stub": StubWorkload}[args.workload](device, rank)
     for _ in range(max(args.warmup, 1)):
         wl.step()
+    ranks_seen, _ = kd.ranks_agree(torch.zeros(4, device=device))          # one all_gather: `world` distinct ranks really met
 
     def timed(steps):
         if use_gpu:
@@ -712,6 +752,8 @@ def main():
             "value": round(total_patches / elapsed, 2),
             "unit": "LR patches/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
+            "backend": torch.distributed.get_backend() if world > 1 else "none (1 rank)",
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),

@@ -280,7 +280,7 @@ int kmsr_conv3x3_winov_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const
  * stream of 4-channel steps; each lane computes the 6x6 input transform of its own patch and the output transform of its own
  * 4x4 blocks; pre-transformed weights are loaded straight from L2 into the MFMA operand registers, raw rows arrive by buffer
  * LDS-DMA (zero padding = out-of-range offsets).  Needs W % 4 == 0, 16-byte aligned x / packed_w / out / residual,
- * Cin*H*W*4 < 2 GB per image.  Packed layout [ceil(Cout/64)][ceil(Cin/4)][2 halves][9 groups][2 blocks of 16][64 lanes][4]. */
+ * Cin*H*W*4 < 2 GB per image, Cout <= 1024 (LDS bias table; with or without a bias pointer).  Packed layout [ceil(Cout/64)][ceil(Cin/4)][2 halves][9 groups][2 blocks of 16][64 lanes][4]. */
 size_t kmsr_conv3x3_wino4_packed_weight_floats(int32_t Cin, int32_t Cout);
 int kmsr_conv3x3_wino4_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int32_t Cin, int32_t Cout, float* packed,
                                         void* stream);

@@ -704,7 +704,7 @@ extern "C" int kmsr_conv3x3_wino4_fwd_ex_f32(const kmsr_conv3x3_desc* d, const f
     if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(packed_w) % 16 || reinterpret_cast<uintptr_t>(out) % 16 ||
         reinterpret_cast<uintptr_t>(residual) % 16)
         return fail(KMSR_E_BADARG, "winograd-4x4 conv needs 16-byte aligned input / weights / output / residual");
-    if (bias && d->Cout > QMAX_BIAS) return fail(KMSR_E_UNSUPPORTED, "winograd-4x4 conv stages the bias vector in LDS: Cout <= %d (Cout=%d)", QMAX_BIAS, d->Cout);
+    if (d->Cout > QMAX_BIAS) return fail(KMSR_E_UNSUPPORTED, "winograd-4x4 conv stages the bias vector in LDS: Cout <= %d (Cout=%d)", QMAX_BIAS, d->Cout);
     if ((long long)d->H * d->W * d->Cin * 4 >= (1ll << 31))   // 32-bit byte offsets inside one image of the input
         return fail(KMSR_E_UNSUPPORTED, "winograd-4x4 conv: one input image (Cin*H*W*4 = %lld bytes) exceeds 2 GB", (long long)d->H * d->W * d->Cin * 4);
     if ((long long)d->H * d->W * 4 * QCO >= (1ll << 31))      // 32-bit byte offsets inside one 64-channel output group

@@ -11,13 +11,14 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
-    Returns (rank, world_size, local_rank).  A single process (WORLD_SIZE unset or 1) needs no group."""
+    Returns (rank, world_size, local_rank).  A single process (WORLD_SIZE unset or 1) needs no group; force=True creates the
+    (legal) one-rank group anyway -- the RCCL smoke test on a one-GPU box."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -45,6 +46,48 @@ def sample_base(local_batch, rank=None):
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
     return int(rank) * int(local_batch)
+
+
+def batch_offsets(local_batch, device="cpu"):
+    """(global index of this rank's first sample, global batch) from ONE all_gather of the ranks' local batch sizes
+    (exclusive prefix sum).  The form for ragged shards (a short last batch, ranks with different shard sizes), where
+    rank * local_batch would overlap or leave gaps in the global sample addressing; collective, so every rank calls it."""
+    if not dist.is_initialized():
+        return 0, int(local_batch)
+    t = torch.tensor([int(local_batch)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(sizes, t)
+    sizes = [int(v.item()) for v in sizes]
+    return sum(sizes[:dist.get_rank()]), sum(sizes)
+
+
+def assert_equal_batch(local_batch, device="cpu"):
+    """One-time guard for callers that address noise with sample_base(local_batch) = rank * local_batch: that is only a
+    partition of the global batch when every rank holds the same number of samples.  Raises on every rank otherwise."""
+    if not dist.is_initialized():
+        return
+    t = torch.tensor([int(local_batch), -int(local_batch)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    lo, hi = -int(t[1].item()), int(t[0].item())
+    if lo != hi:
+        raise ValueError(f"data-parallel ranks hold different batch sizes ({lo} .. {hi}): rank * local_batch does not address the "
+                         "global samples; pass explicit offsets (dist.batch_offsets) as the module's `sample_addr`")
+
+
+def ranks_agree(t):
+    """(ranks seen, all equal) for a tensor that must be bit-identical on every rank (the averaged flat gradient after the
+    step's all-reduce; broadcast weights): one all_gather of (rank, int64 sum of the raw 32-bit words, int64 sum of the words
+    weighted by position mod 8191).  bench.py prints `ranks seen` so the driver's multi-GPU record proves N ranks met."""
+    if not dist.is_initialized():
+        return 1, True
+    w = t.detach().contiguous().view(-1).view(torch.int32).to(torch.int64)
+    pos = torch.arange(w.numel(), device=w.device, dtype=torch.int64) % 8191 + 1
+    mine = torch.stack([torch.tensor(dist.get_rank(), device=w.device, dtype=torch.int64), w.sum(), (w * pos).sum()])
+    got = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, mine)
+    got = torch.stack(got).cpu()
+    seen = len(set(int(r) for r in got[:, 0]))
+    return seen, bool((got[:, 1:] == got[0, 1:]).all())
 
 
 def rank():
@@ -82,9 +125,16 @@ class GradBucket:
     and launches its asynchronous all-reduce the moment the slice is complete (RCCL runs it on its own stream behind the
     kernels already queued), while backward goes on with the earlier layers.  finish() launches whatever is left (the first
     slice; slices with unused parameters), waits and scales.  With a 6 MB gradient two slices are enough: each message stays
-    large enough to be bandwidth- rather than latency-bound on the point-to-point xGMI links."""
+    large enough to be bandwidth- rather than latency-bound on the point-to-point xGMI links.
 
-    def __init__(self, params, chunks=2):
+    Contract of the overlap: between zero(backwards=n) and finish() exactly n backward passes accumulate into the bucket (n = 1
+    unless the step uses gradient-accumulation micro-steps or back-propagates several losses separately); a slice is launched
+    when its parameters have received their n-th gradient.  A hook that fires for a slice already in flight (more backward
+    passes than declared) raises instead of silently adding local gradients to a reduced slice.  `always_reduce=True` runs
+    the collective at world size 1 as well (the RCCL smoke test: the sum over one rank is the identity)."""
+
+    def __init__(self, params, chunks=2, always_reduce=False):
+        self.always_reduce = bool(always_reduce)
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
@@ -116,7 +166,7 @@ class GradBucket:
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _distributed(self):
-        return dist.is_initialized() and dist.get_world_size() > 1
+        return dist.is_initialized() and (dist.get_world_size() > 1 or self.always_reduce)
 
     def _launch(self, k):
         _, _, a, b = self._slices[k]
@@ -126,16 +176,21 @@ class GradBucket:
         if not self._armed:
             return
         k = self._slice_of[id(p)]
+        if self._works[k] is not None:
+            self._armed = False
+            raise RuntimeError("GradBucket: a gradient arrived for a slice whose all-reduce is already in flight -- more backward "
+                               "passes than zero(backwards=n) declared; the averaged gradients would be wrong")
         self._pending[k] -= 1
-        if self._pending[k] == 0 and self._works[k] is None:
+        if self._pending[k] == 0:
             self._launch(k)
 
-    def zero(self):
-        """Clear the gradients and arm the overlap hooks for the backward pass that follows."""
+    def zero(self, backwards=1, overlap=True):
+        """Clear the gradients and arm the overlap hooks for the `backwards` backward passes that follow (overlap=False: no
+        hook launches anything, finish() / all_reduce_mean() reduce the whole bucket)."""
         self.flat.zero_()
-        self._pending = [b - a for a, b, _, _ in self._slices]
+        self._pending = [(b - a) * max(int(backwards), 1) for a, b, _, _ in self._slices]
         self._works = [None] * len(self._slices)
-        self._armed = self._distributed()
+        self._armed = bool(overlap) and self._distributed()
 
     def launched(self):
         """Slices whose all-reduce has already been launched (by the hooks, during backward)."""

@@ -101,7 +101,12 @@ class ContentAdaptiveDegradation(nn.Module):
         #                           addressed globally (dist.sample_base: rank r's batch is samples r*B .. r*B+B-1 of the step), so
         #                           data-parallel ranks draw different eps fields and the fields do not depend on the world size
         self.noise_offset = 0
+        self.sample_addr = None   # (first global sample, step) of this rank's batch, set by a trainer whose ranks hold unequal or
+        #                           round-robin shards (dist.batch_offsets); None = equal contiguous blocks, rank * B
         self.downscale = 4        # train_gemini.py:134  out[:, :, ::4, ::4]
+
+    def _sample_addr(self, B):
+        return self.sample_addr if self.sample_addr is not None else (kd.sample_base(B), 1)
 
     def get_effective_kernels(self):
         """:68-80 softmax over the 169 taps of every (kernel, band)."""
@@ -131,7 +136,7 @@ class ContentAdaptiveDegradation(nn.Module):
         batch_kernels = torch.einsum('bk, kchw -> bchw', weights, valid_kernels)    # :112
         batch_sigmas = torch.einsum('bk, kc -> bc', weights, valid_sigmas)          # :115
         out = DegradeFunction.apply(x.detach(), batch_kernels, batch_sigmas, self.downscale, "zero",
-                                    self.noise_seed, self.noise_offset, kd.sample_base(x.shape[0]), 1)
+                                    self.noise_seed, self.noise_offset, *self._sample_addr(x.shape[0]))
         self.noise_offset += 1
         return out, weights, valid_kernels
 
@@ -143,18 +148,19 @@ class ContentAdaptiveDegradation(nn.Module):
         valid_kernels = self.get_effective_kernels()                                # :107
         valid_sigmas = self.get_effective_sigmas()                                  # :108
         one_hot = bool(((weights == 0) | (weights == 1)).all()) and bool((weights.sum(dim=1) == 1).all())
+        base, step = self._sample_addr(B)
         if one_hot:
             # hard selection: einsum('bk,kchw->bchw') with one-hot weights IS a gather (:112-115)
             out = degrade_batch(x, valid_kernels, self.downscale, down="stride", pad="zero", normalize=False,
                                 kernel_idx=weights.argmax(dim=1).to(torch.int32), sigma=valid_sigmas, noise="gaussian",
-                                seed=self.noise_seed, offset=self.noise_offset, sample_base=kd.sample_base(B),
+                                seed=self.noise_seed, offset=self.noise_offset, sample_base=base, sample_step=step,
                                 validate_idx=False)        # an argmax over the K logits is in [0, K) by construction
         else:
             batch_kernels = torch.einsum('bk, kchw -> bchw', weights, valid_kernels)   # :112
             batch_sigmas = torch.einsum('bk, kc -> bc', weights, valid_sigmas)        # :115
             out = degrade_batch(x, batch_kernels, self.downscale, down="stride", pad="zero", normalize=False,
                                 sigma=batch_sigmas, noise="gaussian", seed=self.noise_seed,
-                                offset=self.noise_offset, sample_base=kd.sample_base(B))
+                                offset=self.noise_offset, sample_base=base, sample_step=step)
         self.noise_offset += 1
         return out, weights, valid_kernels
 
@@ -169,24 +175,26 @@ class NoiseEstimator(nn.Module):
         self.log_sigma = nn.Parameter(torch.log(torch.full(size=(channels,), fill_value=init_sigma)))
         self.noise_seed = 0
         self.noise_offset = 0
+        self.sample_addr = None   # see ContentAdaptiveDegradation.sample_addr
 
     def forward(self, x, eps=None):
         """-> (x + sigma * eps, sigma).  eps: the unit-variance field of the HIP counter-based generator (or a caller-supplied
         one); with autograd enabled the result carries gradients to x and log_sigma like the reference's (:219-224)."""
         sigma = torch.clamp(torch.exp(self.log_sigma), min=1e-5, max=self.sigma_max)      # :222
         one = torch.ones((1, x.shape[1], 1, 1), device=x.device)
+        base, step = self.sample_addr if self.sample_addr is not None else (kd.sample_base(x.shape[0]), 1)
         if torch.is_grad_enabled() or eps is not None:
             if eps is None:
                 with torch.no_grad():     # identity blur of zeros + unit-sigma Gaussian epilogue = the eps field itself
                     eps = degrade_batch(torch.zeros_like(x), one, 1, down="stride", pad="zero", normalize=False,
                                         sigma=torch.ones((1, x.shape[1]), device=x.device), noise="gaussian",
                                         seed=self.noise_seed, offset=self.noise_offset,
-                                        sample_base=kd.sample_base(x.shape[0]))
+                                        sample_base=base, sample_step=step)
                 self.noise_offset += 1
             return x + eps * sigma.view(1, -1, 1, 1), sigma
         # identity blur (1x1 kernel, stride 1) + Gaussian epilogue of the fused kernel
         out = degrade_batch(x, one, 1, down="stride", pad="zero", normalize=False, sigma=sigma.view(1, -1),
                             noise="gaussian", seed=self.noise_seed, offset=self.noise_offset,
-                            sample_base=kd.sample_base(x.shape[0]))
+                            sample_base=base, sample_step=step)
         self.noise_offset += 1
         return out, sigma

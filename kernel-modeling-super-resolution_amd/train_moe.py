@@ -105,6 +105,8 @@ def train_moe(model, D, patches, real_ds, total_iters=5000, lr=1e-4, temp_range=
     for i in range(total_iters):
         if batch_fn is not None:
             patches, real_ds = batch_fn(i)
+        if i == 0 and getattr(model, "sample_addr", None) is None:
+            kd.assert_equal_batch(patches.shape[0], device=patches.device)     # noise is addressed as global sample rank * B + n
         temp = float(temps[i])
         # ---- discriminator step (:178-189)
         with torch.no_grad():

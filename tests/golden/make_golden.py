@@ -6,7 +6,7 @@ output/single_kernel/kernelgan_out*/kernel_*.npy).
 
 Run once in the build container (the GPU box never sees /root/reference):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [--out DIR]
 
 What gets written is DATA only (inputs, expected outputs, re-serialised weights) --
 never reference source text.  Each .npz notes the reference file:line that produced it.
@@ -277,11 +277,6 @@ def main():
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f"{f:28s} {os.path.getsize(os.path.join(OUT, f)) / 1024:9.1f} KiB")
-
-
-if __name__ == "__main__" and not ({"--patch-cutter", "--moe-backward", "--kernelgan-train", "--f64-truth"} & set(sys.argv)):
-    main()
-    make_f64_truth_golden()
 
 
 def patch_cutter_scene(seed=0, H=700, W=900):
@@ -597,13 +592,27 @@ def make_f64_truth_golden():
             print(f"  reference fp32 vs float64  {k_:60s} {np.abs(TR[k_[7:]] - out[k_]).max() / np.abs(out[k_]).max():.2e}")
 
 
-if __name__ == "__main__" and "--f64-truth" in sys.argv:
-    make_f64_truth_golden()
-elif __name__ == "__main__" and "--kernelgan-train" in sys.argv:
-    make_kernelgan_train_golden()
-elif __name__ == "__main__" and "--moe-backward" in sys.argv:
-    make_moe_backward_golden()
-elif __name__ == "__main__":
-    make_patch_cutter_golden()
-    make_moe_backward_golden()
-    make_kernelgan_train_golden()
+if __name__ == "__main__":
+    # `--out DIR` writes somewhere else (tests/test_oracle_golden.py::test_make_golden_reproduces_fixtures regenerates every
+    # fixture into a tmp dir and compares with the committed ones); one flag regenerates one family, no flag everything, in
+    # dependency order (kernelgan.npz -> kernelgan_train.npz, moe_backward.npz -> f64_truth.npz).
+    if "--out" in sys.argv:
+        OUT = os.path.abspath(sys.argv[sys.argv.index("--out") + 1])
+        os.makedirs(OUT, exist_ok=True)
+    if "--f64-truth" in sys.argv:
+        make_f64_truth_golden()
+    elif "--kernelgan-train" in sys.argv:
+        make_kernelgan_train_golden()
+    elif "--moe-backward" in sys.argv:
+        make_moe_backward_golden()
+    elif "--patch-cutter" in sys.argv:
+        make_patch_cutter_golden()
+    elif "--base" in sys.argv:
+        main()
+    else:
+        # every family in a fresh interpreter: ATen's fp32 / fp64 reductions depend in their last bits on the thread-pool
+        # state an earlier generator leaves behind (measured: 1e-7 / 1e-15 relative), and the committed fixtures are the
+        # stand-alone runs of each flag
+        import subprocess
+        for flag in ("--base", "--patch-cutter", "--moe-backward", "--kernelgan-train", "--f64-truth"):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), flag, "--out", OUT])

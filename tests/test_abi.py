@@ -38,6 +38,37 @@ def test_struct_layout_matches_header():
     assert L.DegradeDesc.noise_sample_base.offset == 96 and L.DegradeDesc.noise_sample_step.offset == 100
 
 
+_CTYPE_OF = {"int32_t": C.c_int32, "uint32_t": C.c_uint32, "int64_t": C.c_int64, "uint64_t": C.c_uint64}
+
+
+def _header_struct_fields(name):
+    """(field, ctype) list of `typedef struct <name> {...}` as include/kmsr.h declares it."""
+    src = open(os.path.join(ROOT, "include", "kmsr.h")).read()
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for ty, names in re.findall(r"\b(u?int(?:32|64)_t)\s+([^;]+);", body):
+        out += [(n.strip(), _CTYPE_OF[ty]) for n in names.split(",")]
+    return out
+
+
+def test_integration_md_binding_matches_header_and_lib():
+    """The ctypes stub INTEGRATION.md section B tells a maintainer to copy must be the struct the library reads
+    (round 3: the document lagged the header by two fields)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    snippet = re.search(r"class DegradeDesc\(C\.Structure\):.*?_fields_ = (\[.*?\])\s*(?:#[^\n]*)?\n\n", doc, flags=re.S).group(1)
+    snippet = re.sub(r"#[^\n]*", "", snippet)
+    doc_fields = eval(snippet, {"C": C})                       # a list literal of (name, C.c_*) pairs, our own document
+    lib_fields = [(n, t) for n, t in L.DegradeDesc._fields_]
+    assert doc_fields == lib_fields, "INTEGRATION.md DegradeDesc differs from _lib.DegradeDesc"
+    assert lib_fields == _header_struct_fields("kmsr_degrade_desc"), "_lib.DegradeDesc differs from include/kmsr.h"
+
+    class Doc(C.Structure):
+        _fields_ = doc_fields
+    assert C.sizeof(Doc) == C.sizeof(L.DegradeDesc) == 104
+    assert [(n, t) for n, t in L.Conv3x3Desc._fields_] == _header_struct_fields("kmsr_conv3x3_desc")
+
+
 def _desc(**kw):
     d = L.DegradeDesc()
     d.N, d.C, d.H, d.W = 1, 5, 512, 512
@@ -103,6 +134,22 @@ def test_upsampler_frame_argument_checks_without_gpu():
     assert call(0x1000, 1, 64, 16, 16, 3, 0x1000, 0x1000, 0x1008) == L.KMSR_E_BADARG        # output not 16-byte aligned
     assert call(0x1000, 64, 64, 512, 512, 3, 0x1000, 0x1000, 0x1000) == L.KMSR_E_UNSUPPORTED
     assert b"2 GB" in lib.kmsr_last_error()
+
+
+def test_wino4_argument_checks_without_gpu():
+    """kmsr_conv3x3_wino4_fwd_f32 rejects Cout beyond its LDS bias table with AND without a bias pointer (the epilogue reads the
+    table either way: round-3 advisor finding), plus the alignment / width rules, before any launch."""
+    lib = L.load()
+    d = L.Conv3x3Desc()
+    d.N, d.Cin, d.H, d.W, d.Cout, d.stride = 1, 64, 16, 16, 2048, 1
+    p = lambda a: C.c_void_p(a)
+    assert lib.kmsr_conv3x3_wino4_fwd_f32(d, p(0x1000), p(0x1000), None, None, p(0x1000), None) == L.KMSR_E_UNSUPPORTED
+    assert b"Cout <=" in lib.kmsr_last_error()
+    assert lib.kmsr_conv3x3_wino4_fwd_f32(d, p(0x1000), p(0x1000), p(0x1000), None, p(0x1000), None) == L.KMSR_E_UNSUPPORTED
+    d.Cout, d.W = 64, 18
+    assert lib.kmsr_conv3x3_wino4_fwd_f32(d, p(0x1000), p(0x1000), None, None, p(0x1000), None) == L.KMSR_E_UNSUPPORTED
+    d.W = 16
+    assert lib.kmsr_conv3x3_wino4_fwd_f32(d, p(0x1004), p(0x1000), None, None, p(0x1000), None) == L.KMSR_E_BADARG
 
 
 def test_no_cpu_fallback():

@@ -28,6 +28,7 @@ def test_bench_gpus_2_launches_two_ranks():
     one = _line(_run(["--gpus", "1", "--steps", "20", "--warmup", "2"]))
     two = _line(_run(["--gpus", "2", "--steps", "20", "--warmup", "2"]))
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["steps"] == 20 and two["warmup"] == 2
+    assert one["ranks_seen"] == 1 and two["ranks_seen"] == 2 and two["backend"] == "gloo"      # an all_gather heard from 2 distinct ranks
     assert two["scaling"] == "weak" and two["config"]["workload"] == "stub_sleep5ms_b16"
     for r in (one, two):        # value = patches of ALL ranks / max-over-ranks wall time
         assert abs(r["value"] - 16 * r["n_gpus"] * 1e3 / r["ms_per_step"]) < 1e-2 * r["value"]
@@ -40,3 +41,12 @@ def test_bench_launcher_reports_a_failed_rank():
     proc = _run(["--gpus", "2", "--steps", "3", "--warmup", "1"], KMSR_BENCH_STUB_FAIL_RANK="1")
     assert proc.returncode != 0
     assert not [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]     # no result line from a broken job
+
+
+def test_bench_refuses_gpus_world_size_mismatch():
+    """Under an external launcher whose WORLD_SIZE differs from --gpus the run must not print a line (round-3 advisor finding:
+    it used to warn and go on with n_gpus = the launcher's value)."""
+    e = dict(os.environ, KMSR_BENCH_BACKEND="gloo", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stub", "--no-cpu-baseline", "--gpus", "2",
+                           "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=e, timeout=120)
+    assert proc.returncode != 0 and "WORLD_SIZE=1" in proc.stderr and not proc.stdout.strip()

@@ -62,6 +62,39 @@ def _worker(rank, world, port, q):
     bucket.finish()
     for a, b in zip(net.parameters(), ref.parameters()):
         assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-7)
+    assert kd.ranks_agree(bucket.flat) == (world, True)            # averaged gradients are bit-identical on all ranks
+    assert kd.ranks_agree(bucket.flat + rank) == (world, False)
+    # (3c) two backward passes into one bucket (gradient-accumulation micro-steps): declared with zero(backwards=2), the slices are
+    #      launched only after their parameters' SECOND gradient; the mean equals the single-process sum of both micro-batch losses
+    bucket.zero(backwards=2)
+    torch.nn.functional.mse_loss(net(x_all[sl][:1]), y_all[sl][:1]).backward()
+    assert bucket.launched() == 0
+    torch.nn.functional.mse_loss(net(x_all[sl][1:]), y_all[sl][1:]).backward()
+    assert bucket.launched() >= 1
+    bucket.finish()
+    ref.zero_grad()
+    for r_ in range(world):
+        for m_ in range(2):
+            i_ = r_ * 2 + m_
+            (torch.nn.functional.mse_loss(ref(x_all[i_:i_ + 1]), y_all[i_:i_ + 1]) / world).backward()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-7)
+    # (3d) an UNDECLARED second backward must not silently add local gradients to a slice that is already reduced / in flight
+    bucket.zero()
+    torch.nn.functional.mse_loss(net(x_all[sl]), y_all[sl]).backward()
+    with pytest.raises(RuntimeError, match="already in flight"):
+        torch.nn.functional.mse_loss(net(x_all[sl]), y_all[sl]).backward()
+    bucket.finish()                                  # drains what was launched; the bucket is reusable afterwards
+    bucket.zero(overlap=False)                       # opt-out: nothing is launched from the hooks
+    torch.nn.functional.mse_loss(net(x_all[sl]), y_all[sl]).backward()
+    torch.nn.functional.mse_loss(net(x_all[sl]), y_all[sl]).backward()
+    assert bucket.launched() == 0
+    bucket.finish()
+    # (3e) ragged shards: explicit global sample offsets from one all_gather; the equal-batch guard trips on every rank
+    assert kd.batch_offsets(3 + rank) == (0 if rank == 0 else 3, 7)
+    kd.assert_equal_batch(4)
+    with pytest.raises(ValueError, match="different batch sizes"):
+        kd.assert_equal_batch(4 + rank)
     # (4) world-size-invariant noise: the counter-based Gaussian stream is addressed by the GLOBAL sample index
     #     (kd.sample_base = rank * local batch), so the ranks' fields differ AND their concatenation is bit for bit the field a
     #     single process draws for the whole batch (round-2 advisor finding)
