@@ -443,16 +443,17 @@ class TrainWorkload:
         self.fwd_flops_per_patch = self.net.flops_per_lr_pixel() * h * w
         self.noise_seed = 42
         self.sample_base = kd.sample_base(batch)  # rank r holds global samples r*B .. r*B+B-1: independent eps per sample, world-size invariant
-        # MFMA FLOPs the step ISSUES.  F -> F (2 nb + 1) and F -> 4F layers: forward and data gradient on the Winograd F(4x4,3x3) kernel
-        # (algorithmic / 4), weight gradient in the F(2x2,3x3) domain (/ 2.25); the head's weight gradient F(2x2,3x3), its forward and
-        # the tail's three legs direct.  The head has no data gradient (its input is data).
+        # MFMA FLOPs the step ISSUES.  F -> F (2 nb + 1) and F -> 4F layers: forward, data gradient AND (round 4) weight gradient in the
+        # Winograd F(4x4,3x3) domain (algorithmic / 4); the head's weight gradient F(4x4,3x3) too, its forward and the tail's three
+        # legs direct.  The head has no data gradient (its input is data).
         F_, Cc, nb = self.net.n_feats, C, len(self.net.body)
         ff_px = 18.0 * (2 * nb + 1) * F_ * F_                                      # per LR pixel: body + body_tail
         up_px = 18.0 * F_ * 4 * F_ * (1 + 4)                                       # up1 + up2 (at 2x)
         wino_px = ff_px + up_px
         head_px, tail_px = 18.0 * Cc * F_, 18.0 * F_ * Cc * 16                     # head; tail (at 4x)
         f4 = 1 / 4.0 if Conv3x3Function.use_winograd4 else 1 / 2.25
-        self.issued_flops_per_patch = (wino_px * (2 * f4 + 1 / 2.25) + head_px * (1 + 1 / 2.25) + 3 * tail_px) * h * w
+        wg = 1 / 4.0                                                               # conv3x3_wgrad_wino4_kernel (W % 4 == 0, Cout > 32)
+        self.issued_flops_per_patch = (wino_px * (2 * f4 + wg) + head_px * (1 + wg) + 3 * tail_px) * h * w
         self.algorithmic_flops_per_patch = (3 * wino_px + 2 * head_px + 3 * tail_px) * h * w
         assert abs((wino_px + head_px + tail_px) * h * w - self.fwd_flops_per_patch) < 1e-6 * self.fwd_flops_per_patch
 
@@ -476,9 +477,9 @@ class TrainWorkload:
         iss = self.issued_flops_per_patch * self.B / (step_ms * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": "whole training step (fwd + dgrad + wgrad conv3x3 kernels)", "achieved": round(iss, 2),
                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(iss / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "what": "achieved = MFMA FLOPs ISSUED per step (forward and data-gradient launches of the F->F / F->4F layers on Winograd "
-                        "F(4x4,3x3): algorithmic / 4; weight gradients in the F(2x2,3x3) domain: / 2.25; head forward and the tail direct) / step "
-                        "time -- includes every non-conv pass of the step",
+                "what": "achieved = MFMA FLOPs ISSUED per step (forward, data-gradient and weight-gradient launches of the F->F / F->4F layers "
+                        "in the Winograd F(4x4,3x3) domain: algorithmic / 4; head forward and the tail direct) / step time -- includes every "
+                        "non-conv pass of the step",
                 "issued_flops_per_step": self.issued_flops_per_patch * self.B,
                 "algorithmic_flops_per_step": self.algorithmic_flops_per_patch * self.B,
                 "algorithmic_tflops": round(alg, 2), "algorithmic_over_peak": round(alg / F32_MFMA_PEAK_TFLOPS, 4),

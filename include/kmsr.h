@@ -172,6 +172,9 @@ typedef struct kmsr_conv3x3_desc {
 #define KMSR_CONV_FLAG_RELU_MASK 1u
 /* kmsr_conv3x3_wgrad_f32 only: take the direct (36 products per tap set) kernel even where the Winograd-domain one applies */
 #define KMSR_CONV_FLAG_WGRAD_DIRECT 2u
+/* kmsr_conv3x3_wgrad_f32 only: skip the F(4x4,3x3)-domain kernel (round 4, the default where it applies) and take the
+ * F(2x2,3x3)-domain one where that applies -- kept as the cross-check of the new kernel (tests) and for A/B timing */
+#define KMSR_CONV_FLAG_WGRAD_WINO2 4u
 
 /* number of floats in the packed weight buffer for (Cin, Cout) */
 size_t kmsr_conv3x3_packed_weight_floats(int32_t Cin, int32_t Cout);
@@ -224,10 +227,12 @@ int kmsr_compose_kernels_f32(const float* weights, const float* scales, int32_t 
  *   weight gradient: dw[co,ci,u,v] = sum_{n,y,x} dy[n,co,y,x] * x[n,ci,y+u-1,x+v-1]      (zero padded x)
  *                    fp32 MFMA, persistent workgroups accumulate slabs in registers, partial slabs are written to the
  *                    workspace and summed by a second kernel in a FIXED order (bit-reproducible, no float atomics).
- *                    Even H, W % 4 == 0 with Cout > 32 are computed in the Winograd F(2x2,3x3) domain:
- *                    dg = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G -- 16 products per (co, ci, 2x2 tile) instead of 36,
- *                    slabs of 16 x 64 x 64; other shapes (and d->flags & KMSR_CONV_FLAG_WGRAD_DIRECT) accumulate
- *                    64 x 64 x 9 slabs tap by tap.  Same result within fp32 rounding (tests: 2e-5 of max|dw| vs float64).
+ *                    W % 4 == 0, H >= 4 with Cout > 32 are computed in the Winograd F(4x4,3x3) domain (round 4):
+ *                    dg = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G -- 36 products per (co, ci, 4x4 tile) instead of 144,
+ *                    slabs of 36 x 64 x 32 (x / dy 16-byte aligned); with KMSR_CONV_FLAG_WGRAD_WINO2, even H, W % 4 == 0 and
+ *                    Cout > 32 take the F(2x2,3x3) form (16 products per 2x2 tile instead of 36, slabs of 16 x 64 x 64);
+ *                    other shapes (and d->flags & KMSR_CONV_FLAG_WGRAD_DIRECT) accumulate 64 x 64 x 9 slabs tap by tap.
+ *                    Same result within fp32 rounding (tests: 2e-5 of max|dw| vs float64).
  *   bias gradient  : a plain reduction of dy; left to the caller (torch.sum).
  * d describes the FORWARD conv (N,Cin,H,W,Cout; stride must be 1; relu/pixel_shuffle ignored).
  * ========================================================================================== */

@@ -55,6 +55,7 @@ class ConvKDesc(C.Structure):
 CONVK_REFLECT, CONVK_ZERO = 0, 1
 CONV_FLAG_RELU_MASK = 1
 CONV_FLAG_WGRAD_DIRECT = 2
+CONV_FLAG_WGRAD_WINO2 = 4
 
 _lib = None
 

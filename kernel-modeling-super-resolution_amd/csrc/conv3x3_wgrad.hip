@@ -359,12 +359,17 @@ int wgrad_blocks(const kmsr_conv3x3_desc* d) {
 bool wgrad_wino_eligible(const kmsr_conv3x3_desc* d);
 size_t wgrad_wino_workspace_bytes(const kmsr_conv3x3_desc* d);
 int wgrad_wino_launch(const kmsr_conv3x3_desc* d, const float* x, const float* dy, float* dw, float* ws, hipStream_t stream);
+// Winograd F(4x4,3x3)-domain path (conv3x3_wgrad_wino4.hip): W % 4 == 0, H >= 4 and Cout > 32 -- tried first
+bool wgrad_wino4_eligible(const kmsr_conv3x3_desc* d);
+size_t wgrad_wino4_workspace_bytes(const kmsr_conv3x3_desc* d);
+int wgrad_wino4_launch(const kmsr_conv3x3_desc* d, const float* x, const float* dy, float* dw, float* ws, hipStream_t stream);
 }  // namespace kmsr
 
 using namespace kmsr;
 
 extern "C" size_t kmsr_conv3x3_wgrad_workspace_bytes(const kmsr_conv3x3_desc* d) {
     if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return 0;
+    if (wgrad_wino4_eligible(d)) return wgrad_wino4_workspace_bytes(d);
     if (wgrad_wino_eligible(d)) return wgrad_wino_workspace_bytes(d);
     return (size_t)ceil_div(d->Cout, 64) * ceil_div(d->Cin, 64) * wgrad_blocks(d) * 9 * 64 * 64 * sizeof(float);
 }
@@ -380,7 +385,9 @@ extern "C" int kmsr_conv3x3_wgrad_f32(const kmsr_conv3x3_desc* d, const float* x
     if ((long long)std::max(d->Cin, d->Cout) * d->H * d->W >= (1ll << 31)) return fail(KMSR_E_UNSUPPORTED, "per-image tensor exceeds 2^31 elements");
     if ((long long)d->H * d->W * 4 * 64 >= (1ll << 31))       // buffer-load byte offsets of one 64-channel group are 32-bit
         return fail(KMSR_E_UNSUPPORTED, "wgrad: H*W = %lld exceeds 2^23 pixels per plane", (long long)d->H * d->W);
-    if (d->flags & ~(uint32_t)KMSR_CONV_FLAG_WGRAD_DIRECT) return fail(KMSR_E_BADARG, "wgrad: unknown flags 0x%x", d->flags);
+    if (d->flags & ~(uint32_t)(KMSR_CONV_FLAG_WGRAD_DIRECT | KMSR_CONV_FLAG_WGRAD_WINO2)) return fail(KMSR_E_BADARG, "wgrad: unknown flags 0x%x", d->flags);
+    if (wgrad_wino4_eligible(d))
+        return wgrad_wino4_launch(d, x, dy, dw, static_cast<float*>(workspace), static_cast<hipStream_t>(stream_));
     if (wgrad_wino_eligible(d))
         return wgrad_wino_launch(d, x, dy, dw, static_cast<float*>(workspace), static_cast<hipStream_t>(stream_));
     WgradParams p{};

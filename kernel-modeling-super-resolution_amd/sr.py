@@ -177,9 +177,10 @@ def conv3x3(x, packed_w, cout, bias=None, relu=False, residual=None, pixel_shuff
     return out
 
 
-def conv3x3_wgrad(x, dy, direct=False):
+def conv3x3_wgrad(x, dy, direct=False, wino2=False):
     """dw[co,ci,u,v] = sum_{n,y,x} dy[n,co,y,x] * x[n,ci,y+u-1,x+v-1]  (stride 1, zero padding 1) -> [Cout,Cin,3,3].
-    Even H, W % 4 == 0 with Cout > 32 run in the Winograd F(2x2,3x3) domain (16 products per tile instead of 36) unless direct=True."""
+    W % 4 == 0, H >= 4 with Cout > 32 run in the Winograd F(4x4,3x3) domain (36 products per 4x4 tile instead of 144); wino2=True
+    takes the F(2x2,3x3)-domain kernel instead (even H: 16 products per 2x2 tile), direct=True the tap-by-tap kernel."""
     lib = L.load()
     x = x.contiguous()
     dy = dy.contiguous()
@@ -189,7 +190,7 @@ def conv3x3_wgrad(x, dy, direct=False):
     Cout = dy.shape[1]
     d = L.Conv3x3Desc()
     d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, Cin, H, W, Cout, 1
-    d.flags = L.CONV_FLAG_WGRAD_DIRECT if direct else 0
+    d.flags = L.CONV_FLAG_WGRAD_DIRECT if direct else (L.CONV_FLAG_WGRAD_WINO2 if wino2 else 0)
     nbytes = lib.kmsr_conv3x3_wgrad_workspace_bytes(d)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     dw = torch.empty((Cout, Cin, 3, 3), device=x.device, dtype=torch.float32)

@@ -21,7 +21,12 @@ def _rel(a, b):
                                             (2, 64, 33, 45, 5), (1, 100, 5, 70, 7), (1, 8, 1, 1, 1), (2, 64, 6, 64, 20),   # small-Cout kernels (<= 7, <= 32)
                                             # even H, W % 4 == 0 and Cout > 32: the Winograd-domain kernel (partial column blocks, one tile
                                             # row, several channel groups on either side, more stages than workgroups)
-                                            (1, 5, 2, 4, 64), (2, 64, 4, 68, 256), (1, 70, 10, 28, 40), (3, 64, 64, 96, 64), (9, 64, 128, 128, 64)])
+                                            (1, 5, 2, 4, 64), (2, 64, 4, 68, 256), (1, 70, 10, 28, 40), (3, 64, 64, 96, 64), (9, 64, 128, 128, 64),
+                                            # W % 4 == 0, H >= 4, Cout > 32: the F(4x4,3x3)-domain kernel (round 4) -- odd H and H % 4 != 0 (partial
+                                            # last tile row), partial 32-column blocks, channel tails on both sides (ci groups of 32, co groups of 64,
+                                            # odd Cout: the last dy plane pair is half empty), fewer stages than workgroups, several images per range
+                                            (1, 64, 4, 4, 64), (2, 33, 7, 36, 65), (1, 96, 13, 100, 33), (5, 64, 32, 32, 64), (2, 7, 64, 256, 40),
+                                            (40, 64, 16, 32, 64)])
 def test_wgrad_and_dgrad_vs_torch(N, Cin, H, W, Cout, gpu_device):
     g = torch.Generator().manual_seed(N + Cin + Cout)
     x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
@@ -34,6 +39,8 @@ def test_wgrad_and_dgrad_vs_torch(N, Cin, H, W, Cout, gpu_device):
     assert _rel(dw, w.grad) < 2e-5, f"wgrad rel err {_rel(dw, w.grad):.3e}"
     dwd = conv3x3_wgrad(x.detach().float().cuda(), dy.float().cuda(), direct=True)      # the 36-product kernel on the same shape
     assert _rel(dwd, w.grad) < 2e-5, f"direct wgrad rel err {_rel(dwd, w.grad):.3e}"
+    dw2 = conv3x3_wgrad(x.detach().float().cuda(), dy.float().cuda(), wino2=True)       # F(2x2,3x3) domain where it applies (else direct)
+    assert _rel(dw2, w.grad) < 2e-5, f"F(2x2) wgrad rel err {_rel(dw2, w.grad):.3e}"
     dx = conv3x3(dy.float().cuda(), pack_conv3x3_weight(w.detach().float().cuda(), transpose_flip=True), Cin)
     assert _rel(dx, x.grad) < 2e-5, f"dgrad rel err {_rel(dx, x.grad):.3e}"
 

@@ -1,16 +1,31 @@
-#!/usr/bin/env python3
-import os, sys, torch
+"""Weight-gradient kernels on the config-3 layer shapes: F(4x4,3x3) domain (default) vs F(2x2,3x3) (wino2) vs direct.
+usage: python tools/time_wgrad.py [batch]"""
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from kmsr_amd.sr import conv3x3, conv3x3_wgrad, pack_conv3x3_weight
-torch.cuda.set_device(0)
-for name, N, Cin, H, W, Cout in [("body 64->64 @256^2 x16", 16, 64, 256, 256, 64), ("up2 64->256 @512^2 x4", 4, 64, 512, 512, 256), ("tail 64->3 @1024^2 x4", 4, 64, 1024, 1024, 3)]:
-    x = torch.randn(N, Cin, H, W, device="cuda"); dy = torch.randn(N, Cout, H, W, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda")
-    fl = 2.0 * 9 * N * Cin * Cout * H * W
-    for what, fn in (("wgrad", lambda: conv3x3_wgrad(x, dy)), ("dgrad", lambda: conv3x3(dy, pw, Cin))):
-        pw = pack_conv3x3_weight(w, transpose_flip=True)
-        fn(); torch.cuda.synchronize()
+import torch
+from kmsr_amd.sr import conv3x3_wgrad
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+ONLY = sys.argv[2] if len(sys.argv) > 2 else None          # e.g. "body": that layer only, F(4x4) only
+shapes = [("body 64->64 @256", B, 64, 256, 256, 64), ("up1 64->256 @256", B, 64, 256, 256, 256), ("up2 64->256 @512", B, 64, 512, 512, 256),
+          ("head 5->64 @256", B, 5, 256, 256, 64)]
+for name, N, Cin, H, W, Cout in shapes:
+    if ONLY and not name.startswith(ONLY):
+        continue
+    x = torch.randn(N, Cin, H, W, device="cuda")
+    dy = torch.randn(N, Cout, H, W, device="cuda") * 0.01
+    ref = None
+    for tag, kw in (("F(4x4)", {}), ("F(2x2)", {"wino2": True}), ("direct", {"direct": True})):
+        if (tag == "direct" and Cout == 256 and H == 512) or (ONLY and tag != "F(4x4)"):
+            continue
+        for _ in range(2):
+            dw = conv3x3_wgrad(x, dy, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5): fn()
-        e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / 5
-        print(f"{name:26s} {what}: {ms:8.3f} ms  {fl/ms/1e9:7.1f} TF ({fl/ms/1e9/157.3*100:5.1f}%)")
+        for _ in range(5):
+            dw = conv3x3_wgrad(x, dy, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = dw
+        print(f"{name:18s} {tag:7s} {e0.elapsed_time(e1) / 5:8.3f} ms   max|diff vs F(4x4)| / max|dw| = {float((dw - ref).abs().max() / ref.abs().max()):.2e}", flush=True)
