@@ -30,6 +30,7 @@ from kmsr_amd import _lib as L  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 MFMA / vector peak
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s)
 
 
 def host_cores():
@@ -396,23 +397,45 @@ class SRBf16Workload:
         self.sr = self.ex(self.lr)
 
     def roofline(self, step_ms):
-        from kmsr_amd.sr_bf16 import conv3x3_bf16
-        # dominant kernel timed live on the launch stream: body conv 64->64 with residual at the tile size
-        x = torch.randn(1, self.h, self.w, 64, device=self.lr.device).to(torch.bfloat16)
-        prm = self.ex.body[0][1]
+        """Dominant kernel of the tile, timed live on the launch stream: since round 4 the fused residual block
+        (kmsr_resblock_fwd_bf16: conv1 + ReLU + conv2 + skip in one launch, the intermediate map stays in LDS) -- 16 launches per tile.
+        Two rooflines: HBM (algorithmic bytes = x read once + y written once) and the bf16 matrix pipe (issued MFMA FLOPs incl. the
+        halo-ring recompute: 4 x 180 MFMAs of 32x32x16 per 128 output pixels instead of 4 x 144)."""
+        from kmsr_amd.sr_bf16 import conv3x3_bf16, resblock_bf16
+        dev = self.lr.device
+        x = torch.randn(1, self.h, self.w, 64, device=dev).to(torch.bfloat16)
         out = torch.empty_like(x)
-        conv3x3_bf16(x, prm[0], prm[2], bias=prm[1], residual=x, out=out)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            conv3x3_bf16(x, prm[0], prm[2], bias=prm[1], residual=x, out=out)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
-        ach = self.body_bytes / (ms * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": "conv3x3_bf16_kernel<false> (64->64 + residual @1024x1024, channels-last bf16)",
-                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "algorithmic_bytes_per_launch": self.body_bytes, "kernel_ms": round(ms, 4)}
+        c1, c2 = self.ex.body[0]
+
+        def timed(fn, n=10):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+        fused = self.ex.fuse_resblocks and self.net.n_feats == 64
+        ms_layer = timed(lambda: conv3x3_bf16(x, c2[0], c2[2], bias=c2[1], residual=x, out=out))
+        layer = {"kernel": "conv3x3_bf16_rw_kernel (64->64 + residual @1024x1024, channels-last bf16; one of two launches of the layer-wise block)",
+                 "kernel_ms": round(ms_layer, 4), "GBps": round(self.body_bytes / (ms_layer * 1e-3) / 1e9, 1),
+                 "frac_of_hbm": round(self.body_bytes / (ms_layer * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if not fused:
+            return {"bound": "hbm", "kernel": layer["kernel"], "achieved": layer["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": layer["frac_of_hbm"],
+                    "traffic": None, "algorithmic_bytes_per_launch": self.body_bytes, "kernel_ms": layer["kernel_ms"]}
+        ms = timed(lambda: resblock_bf16(x, c1[0], c1[1], c2[0], c2[1], out=out))
+        block_bytes = 2.0 * 64 * self.h * self.w * 2                                   # x in + y out
+        issued = 4 * 180.0 / 128 * self.h * self.w * 2 * 32 * 32 * 16                  # MFMA FLOPs issued per launch: 4 waves x 180 MFMAs of 32x32x16 per 128-pixel tile
+        ach = block_bytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "resblock_bf16_kernel (conv3x3 + ReLU + conv3x3 + skip, 64 ch @1024x1024, channels-last bf16, one launch per residual block)",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": block_bytes, "kernel_ms": round(ms, 4),
+                "mfma": {"issued_flops_per_launch": issued, "issued_tflops": round(issued / (ms * 1e-3) / 1e12, 1), "peak_tflops": BF16_MFMA_PEAK_TFLOPS,
+                         "frac_of_bf16_mfma_peak": round(issued / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                         "note": "the fused block is bound by instruction issue of one wave per SIMD (MFMA + epilogue VALU share the port) at a "
+                                 "sustained ~1.75 GHz, not by HBM: see DESIGN 4.7c"},
+                "layerwise_launch": layer}
 
 
 class TrainWorkload:
@@ -543,7 +566,8 @@ def secondary_lines(device, rank, world, kd, sync):
     out["sr_bf16"] = {"config": f"configs[3]: {wl.name}, LR [1,{wl.C},{wl.h},{wl.w}] -> SR [1,{wl.C},{wl.H},{wl.W}]", "bf16_tile_ms": round(ms, 3),
                       "value": round(wl.patches_per_step * world / (ms * 1e-3), 2), "unit": "256^2 LR patches/s (all ranks)", "tiles_timed": 5,
                       "tile_ms_rank0": spread(per),
-                      "body_layer_ms": rf["kernel_ms"], "body_layer_frac_of_hbm": rf["frac"], "body_layer_GBps": rf["achieved"],
+                      "body_kernel": rf["kernel"], "body_kernel_ms": rf["kernel_ms"], "body_kernel_frac_of_hbm": rf["frac"], "body_kernel_GBps": rf["achieved"],
+                      "body_kernel_mfma": rf.get("mfma"), "body_layerwise_launch": rf.get("layerwise_launch"),
                       "tile_min_io_GBps": round(io_bytes / (ms * 1e-3) / 1e9, 1)}
     del wl
     torch.cuda.empty_cache()

@@ -410,6 +410,14 @@ int kmsr_conv3x3_bf16_pack_weights(const float* w, int32_t Cin, int32_t Cout, in
 int kmsr_conv3x3_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x_bf16, const void* packed_w_bf16,
                           const float* bias /* [Cout] fp32 (padded) or NULL */, const void* residual_bf16,
                           void* out_bf16, void* stream);
+/* Fused residual block of the bf16 path (round 4): out = x + conv2(relu(conv1(x) + bias1)) + bias2 on channels-last bf16 tensors with
+ * exactly 64 channels ([N,H,W,64]); packed_w1 / packed_w2 from kmsr_conv3x3_bf16_pack_weights(w, 64, 64, 64, 64), biases fp32 [64] or
+ * NULL.  ONE launch instead of two kmsr_conv3x3_fwd_bf16 calls: the intermediate map stays in LDS (conv1 is recomputed on the 1-pixel
+ * halo ring of every 8 x 16 tile), so a block reads x once and writes out once.  Every rounding of the two-launch path is kept
+ * (intermediate rounded to bf16, zero outside the image; conv2 + bias rounded to bf16 before the skip add): the result is
+ * bit-identical to it.  out must not alias x; 16-byte aligned pointers; H*W*128 B < 4 GiB per image. */
+int kmsr_resblock_fwd_bf16(int32_t N, int32_t H, int32_t W, const void* x_bf16, const void* packed_w1_bf16, const float* bias1,
+                           const void* packed_w2_bf16, const float* bias2, void* out_bf16, void* stream);
 int kmsr_conv3x3_pixelshuffle_fwd_bf16(const kmsr_conv3x3_desc* d, const void* x_bf16, const void* packed_w_bf16, const float* bias,
                                        void* out_bf16, void* stream);   /* kmsr_conv3x3_fwd_bf16 with pixel_shuffle = 1 */
 /* Backward legs on the same channels-last bf16 tensors; d describes the FORWARD conv (padded channel counts).

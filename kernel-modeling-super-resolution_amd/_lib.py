@@ -92,6 +92,7 @@ SYMBOLS = {
     "kmsr_conv3x3_bf16_packed_weight_elems": (_sz, [_i32, _i32]),
     "kmsr_conv3x3_bf16_pack_weights": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "kmsr_conv3x3_fwd_bf16": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "kmsr_resblock_fwd_bf16": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kmsr_conv3x3_bf16_pack_weights_dgrad": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "kmsr_conv3x3_dgrad_bf16": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp]),
     "kmsr_conv3x3_wgrad_bf16_workspace_bytes": (_sz, [C.POINTER(Conv3x3Desc)]),

@@ -59,6 +59,25 @@ def conv3x3_bf16(x, packed_w, cout_p, bias=None, relu=False, residual=None, pixe
     return out
 
 
+def resblock_bf16(x, packed_w1, bias1, packed_w2, bias2, out=None):
+    """x [N,H,W,64] bf16 channels-last -> x + conv2(relu(conv1(x) + b1)) + b2 in ONE launch (kmsr_resblock_fwd_bf16): the intermediate
+    map stays in LDS.  Bit-identical to conv3x3_bf16(relu=True) followed by conv3x3_bf16(residual=x)."""
+    lib = L.load()
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.ndim == 4 and x.shape[3] == 64
+    N, H, W, _ = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.data_ptr() != x.data_ptr() and out.shape == x.shape and out.is_contiguous() and out.dtype == torch.bfloat16
+    for pw in (packed_w1, packed_w2):
+        assert pw.dtype == torch.bfloat16 and pw.numel() == lib.kmsr_conv3x3_bf16_packed_weight_elems(64, 64)
+    for b in (bias1, bias2):
+        assert b is None or (b.dtype == torch.float32 and b.numel() >= 64 and b.is_cuda)
+    with torch.cuda.device(x.device):
+        L.check(lib.kmsr_resblock_fwd_bf16(N, H, W, L.ptr(x), L.ptr(packed_w1), L.ptr(bias1), L.ptr(packed_w2), L.ptr(bias2), L.ptr(out),
+                                           L.current_stream()))
+    return out
+
+
 def pack_conv3x3_weight_bf16_dgrad(weight, cin_p, cout_p):
     """Weights of the data-gradient conv (cout_p channels in, cin_p out): w'[ci,co,u,v] = w[co,ci,2-u,2-v], from the fp32 master."""
     lib = L.load()
@@ -183,6 +202,7 @@ class SRNetBF16:
     def __init__(self, net):
         self.net = net
         self.fuse_upsampler = True
+        self.fuse_resblocks = True      # 64-feature nets: one kmsr_resblock_fwd_bf16 launch per residual block (bit-identical to two conv launches)
         self.refresh()
 
     def _prep(self, conv, cin_p, cout_p):
@@ -217,8 +237,13 @@ class SRNetBF16:
         cv = lambda prm, t, **kw: conv3x3_bf16(t, prm[0], prm[2], bias=prm[1], **kw)
         f = cv(self.head, h0)
         h = f
-        for c1, c2 in self.body:
-            h = cv(c2, cv(c1, h, relu=True), residual=h)
+        if self.fuse_resblocks and n.n_feats == 64:
+            pp = [torch.empty_like(h), torch.empty_like(h)]              # ping-pong (the fused kernel is not in-place; f stays intact)
+            for i, (c1, c2) in enumerate(self.body):
+                h = resblock_bf16(h, c1[0], c1[1], c2[0], c2[1], out=pp[i & 1])
+        else:
+            for c1, c2 in self.body:
+                h = cv(c2, cv(c1, h, relu=True), residual=h)
         h = cv(self.body_tail, h, residual=f)
         if self.fuse_upsampler and self.up5 is not None and min(h.shape[1:3]) >= self.FUSE_MIN_SIZE:
             return self._fused_upsampler(h)

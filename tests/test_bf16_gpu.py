@@ -194,3 +194,45 @@ def test_srnet_bf16_fused_upsampler(colors, shape, gpu_device):
     e_f, e_l = float((fus - want).abs().max()) / scale, float((lay - want).abs().max()) / scale
     assert e_f < 3e-2 and e_f <= 1.25 * e_l + 4e-3, f"fused {e_f:.3e} vs layer-wise {e_l:.3e} of scale from the fp32 oracle"
     assert float((fus - lay).abs().max()) < 3e-2 * scale
+
+
+# ------------------------------------------------------------------ fused residual block (kmsr_resblock_fwd_bf16, round 4)
+@pytest.mark.parametrize("N,H,W", [(1, 8, 16), (2, 24, 48), (1, 33, 45), (1, 5, 7), (3, 17, 16), (1, 64, 160), (1, 1, 1)])
+def test_resblock_bf16_bit_identical_to_two_launches(N, H, W, gpu_device):
+    """One launch (intermediate in LDS, conv1 recomputed on each tile's halo ring) must reproduce the two-launch path BIT FOR BIT:
+    same MFMA accumulation order, the intermediate rounded to bf16 and zero outside the image, conv2 + bias rounded before the
+    skip add.  Shapes: one tile, several tiles, ragged right / bottom tiles (H % 8, W % 16 != 0), images smaller than a tile,
+    more tiles than workgroups' first items."""
+    from kmsr_amd.sr_bf16 import resblock_bf16
+    g = torch.Generator().manual_seed(H * 131 + W)
+    x = to_nhwc_bf16((torch.randn(N, 64, H, W, generator=g) * 2).cuda())
+    w1 = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    w2 = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    b1 = torch.randn(64, generator=g).cuda()
+    b2 = torch.randn(64, generator=g).cuda()
+    p1, p2 = pack_conv3x3_weight_bf16(w1.cuda(), 64, 64), pack_conv3x3_weight_bf16(w2.cuda(), 64, 64)
+    t = conv3x3_bf16(x, p1, 64, bias=b1, relu=True)
+    want = conv3x3_bf16(t, p2, 64, bias=b2, residual=x)
+    got = resblock_bf16(x, p1, b1, p2, b2)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), \
+        f"{int((got.view(torch.int16) != want.view(torch.int16)).sum())} of {got.numel()} elements differ"
+    # and against the fp32 reference of the bf16-rounded operands (the two-launch path's own bound: one bf16 ulp per rounding)
+    ref_t = _bf(torch.relu(F.conv2d(_bf(from_nhwc(x, 64).float().cpu()), _bf(w1), b1.cpu(), padding=1)))
+    ref = F.conv2d(ref_t, _bf(w2), b2.cpu(), padding=1) + from_nhwc(x, 64).float().cpu()
+    err = (from_nhwc(got, 64).float().cpu() - ref).abs()
+    assert float(err.max()) <= 0.05 * float(ref.abs().max()) and float((err / (ref.abs() + 1)).mean()) < 4e-3
+    # no bias
+    assert torch.equal(resblock_bf16(x, p1, None, p2, None).view(torch.int16),
+                       conv3x3_bf16(conv3x3_bf16(x, p1, 64, relu=True), p2, 64, residual=x).view(torch.int16))
+
+
+def test_srnet_bf16_fused_resblocks_equal_layerwise(gpu_device):
+    """SRNetBF16 with one launch per residual block == the layer-by-layer body, bit for bit (whole network output)."""
+    torch.manual_seed(3)
+    net = kmsr_amd.SRNet(7, 64, 4, 4).cuda().eval()
+    ex = SRNetBF16(net)
+    x = torch.rand(1, 7, 40, 72, device="cuda") * 80 + 20
+    a = ex(x)
+    ex.fuse_resblocks = False
+    b = ex(x)
+    assert torch.equal(a, b)
