@@ -272,6 +272,10 @@ __global__ void __launch_bounds__(QT, 1) conv3x3_wino4_kernel(const float* __res
     auto read_patch = [&](Patch& P, int k) {                // LDS read k of the 12 (one per MFMA pair inside a step: four waves posting
         const float* rp = lds + QOFF_R + rd_off + pbase;    // all 12 right behind the barrier keep the LDS pipe -- and, in order
         const int r = k >> 1;                               // behind it, every wave's first MFMAs -- busy for ~300 cycles)
+        // (The 4-way bank conflict of the two edge dwords -- all 64 lanes on the 16 banks = 3 mod 4, whatever the plane pitch -- is real:
+        //  59 % of the LDS-active cycles.  Replacing them by ONE dword per row plus two DPP row shifts of the neighbours' quads removed
+        //  83 % of the conflict cycles and made the kernel 1-4 % SLOWER: + 12 VALU per patch on the issue port the MFMAs share, while
+        //  no wave ever waits for these reads (SQ_WAIT_INST_LDS 0.1 % of the wave cycles).  profiles/r04_wino4_dpp_edges_null.log)
         if (k & 1) P.e[r] = f32x2{rp[r * QRCOLS], rp[r * QRCOLS + 5]};
         else P.mid[r] = *reinterpret_cast<const f32x4*>(rp + r * QRCOLS + 1);
     };
