@@ -73,6 +73,28 @@ def static_traffic(kernel_key):
     return out
 
 
+def static_traffic_degrade(shape_key):
+    """Same record, the degradation kernel's entry (two shapes in one command, told apart by the grid size; hash of degrade.hip)."""
+    import glob
+    import hashlib
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic.json")))):
+        try:
+            with open(path) as f:
+                deg = json.load(f).get("degrade")
+            if not deg:
+                continue
+            with open(os.path.join(ROOT, "kernel-modeling-super-resolution_amd", "csrc", deg["kernel_source"]), "rb") as f:
+                sha = hashlib.sha256(f.read()).hexdigest()[:16]
+            rec = deg["shapes"].get(shape_key)
+            if rec and sha == deg["kernel_source_sha256_16"]:
+                return {"traffic": rec["traffic_bytes_per_launch"], "traffic_static": True, "traffic_over_algorithmic_bytes": rec["traffic_over_algorithmic"],
+                        "traffic_source": f"profiles/{os.path.basename(path)} [degrade/{shape_key}] (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; recorded, "
+                                          f"not measured in this run; degrade.hip sha256 {sha} matches)"}
+        except (OSError, KeyError, ValueError):
+            continue
+    return {"traffic": None}
+
+
 def synth_hr(n, c, h, w, device, seed):
     """Synthetic 'Landsat-shaped' TOA radiance tiles: U(20,100), fp32, NaN-free."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -116,10 +138,13 @@ class DegradeWorkload:
 
     def roofline(self, kernel_ms):
         achieved = self.bytes_per_patch * self.patches_per_step / (kernel_ms * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": "degrade_rowstream_kernel<4,13,13,6,6,2>", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "algorithmic_bytes_per_launch": self.bytes_per_patch * self.patches_per_step,
-                "kernel_ms": round(kernel_ms, 4)}
+        out = {"bound": "hbm", "kernel": "degrade_rowstream_kernel<4,13,13,6,6,2>", "achieved": round(achieved, 1),
+               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+               "algorithmic_bytes_per_launch": self.bytes_per_patch * self.patches_per_step,
+               "kernel_ms": round(kernel_ms, 4)}
+        if (self.B, self.C, self.H, self.W) == (32, 5, 1024, 1024):
+            out.update(static_traffic_degrade("northstar_hr32x5x1024x1024"))
+        return out
 
     def cpu_baseline(self, budget_s=12.0):
         """The oracle (CPU restatement of train_gemini.py:124-138) on a bounded sample of the same workload."""
@@ -275,11 +300,13 @@ class DegradeSRWorkload:
             return None
         kernel_ms = ms[len(ms) // 2]
         ach = self.deg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": "degrade_rowstream_kernel (V-B: 13x13 stride 4, zero pad, Philox noise) on HR [16,3,1024,1024]",
-                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "algorithmic_bytes_per_launch": self.deg_bytes_per_launch,
-                "kernel_ms": round(kernel_ms, 4), "launches_timed": len(ms),
-                "what": "HIP events around the kmsr_degrade_f32 call of every instrumented step (tap table already built)"}
+        out = {"bound": "hbm", "kernel": "degrade_rowstream_kernel (V-B: 13x13 stride 4, zero pad, Philox noise) on HR [16,3,1024,1024]",
+               "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+               "traffic": None, "algorithmic_bytes_per_launch": self.deg_bytes_per_launch,
+               "kernel_ms": round(kernel_ms, 4), "launches_timed": len(ms),
+               "what": "HIP events around the kmsr_degrade_f32 call of every instrumented step (tap table already built)"}
+        out.update(static_traffic_degrade("config2_hr16x3x1024x1024"))
+        return out
 
     def roofline_degrade_northstar(self, launches=20):
         """The same fused kernel on north_star's unit of the degradation path (HR [32,5,1024,1024] ->

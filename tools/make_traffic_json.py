@@ -38,6 +38,24 @@ out = {
     "other_kernels": {k[:80]: {"FETCH_SIZE_kb": v["mean_kb"], "WRITE_SIZE_kb": sm["pmc"]["WRITE_SIZE"].get(k, {}).get("mean_kb")}
                       for k, v in sm["pmc"]["FETCH_SIZE"].items()},
 }
+# ---- the degradation kernel of the same command: two shapes under one kernel name, told apart by the grid size
+#      (bench step: HR [16,3,1024,1024] = 48 planes; north-star unit: HR [32,5,1024,1024] = 160 planes)
+byg = sm.get("pmc_by_grid")
+if byg:
+    fg = {k: v for k, v in byg["FETCH_SIZE"].items() if "degrade_rowstream_kernel" in k}
+    grids = sorted(fg, key=lambda k: int(k.rsplit("=", 1)[1]))
+    if len(grids) >= 2:
+        dsrc = f"{R}/kernel-modeling-super-resolution_amd/csrc/degrade.hip"
+        shapes = {"config2_hr16x3x1024x1024": (grids[0], 16 * (4 * 3 * 1024 * 1024 + 4 * 3 * 256 * 256 + 4 * 3 * 169)),
+                  "northstar_hr32x5x1024x1024": (grids[-1], 32 * (4 * 5 * 1024 * 1024 + 4 * 5 * 256 * 256 + 4 * 5 * 169))}
+        deg = {"kernel_source": "degrade.hip", "kernel_source_sha256_16": hashlib.sha256(open(dsrc, "rb").read()).hexdigest()[:16], "shapes": {}}
+        for key, (g, algb) in shapes.items():
+            f, w = fg[g], byg["WRITE_SIZE"][g]
+            tb = f["mean_kb"] * 1024 * 2 + w["mean_kb"] * 1024
+            deg["shapes"][key] = {"kernel_and_grid": g, "launches": f["n"], "FETCH_SIZE_kb_mean": f["mean_kb"], "WRITE_SIZE_kb_mean": w["mean_kb"],
+                                  "traffic_bytes_per_launch": tb, "algorithmic_bytes_per_launch": algb, "traffic_over_algorithmic": tb / algb}
+        out["degrade"] = deg
+        print("degrade traffic / algorithmic:", {k: round(v["traffic_over_algorithmic"], 3) for k, v in deg["shapes"].items()})
 json.dump(out, open(f"{R}/profiles/{rnd}_bench_pmc_traffic.json", "w"), indent=1)
 shutil.copy(max(glob.glob(f"{R}/gpurun_out/{name}/trace/*/*_kernel_stats.csv"), key=os.path.getmtime),   # gpurun MERGES into gpurun_out/: older boxes' directories stay
             f"{R}/profiles/{rnd}_bench_kernel_stats.csv")
