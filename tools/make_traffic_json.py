@@ -43,8 +43,12 @@ out = {
 byg = sm.get("pmc_by_grid")
 if byg:
     fg = {k: v for k, v in byg["FETCH_SIZE"].items() if "degrade_rowstream_kernel" in k}
-    grids = sorted(fg, key=lambda k: int(k.rsplit("=", 1)[1]))
-    if len(grids) >= 2:
+    # grid = waves * 64: planes x 2 strips of 128 LR columns x (256 LR rows / rows_per_chunk) chunks; the library picks 4 rows per chunk for
+    # the 48-plane batch (6144 waves) and 16 for the 160-plane unit (5120 waves)
+    want = {"config2": 48 * 2 * 64 * 64, "northstar": 160 * 2 * 16 * 64}
+    bygrid = {int(k.rsplit("=", 1)[1]): k for k in fg}
+    if all(g in bygrid for g in want.values()):
+        grids = [bygrid[want["config2"]], bygrid[want["northstar"]]]
         dsrc = f"{R}/kernel-modeling-super-resolution_amd/csrc/degrade.hip"
         shapes = {"config2_hr16x3x1024x1024": (grids[0], 16 * (4 * 3 * 1024 * 1024 + 4 * 3 * 256 * 256 + 4 * 3 * 169)),
                   "northstar_hr32x5x1024x1024": (grids[-1], 32 * (4 * 5 * 1024 * 1024 + 4 * 5 * 256 * 256 + 4 * 5 * 169))}
