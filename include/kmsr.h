@@ -272,6 +272,9 @@ int kmsr_conv3x3_wino_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const 
  * output transform is lane-local -- the transformed inputs never go through LDS and the epilogue needs no exchange.
  * Packed layout [ceil(Cout/64)][ceil(Cin/8)][2 steps][4 channel blocks of 16][4][64 lanes][4].  Cout <= 1024 when bias is given
  * (the bias vector is staged in LDS). */
+/* CROSS-CHECK entry points since round 3 (kmsr_conv3x3_winov_*): the F(2x2,3x3) kernel with the transformed inputs in registers.  No default
+ * path takes it any more (the F(4x4,3x3) kernel below serves the same shapes); it stays exported because the tests compare the product kernel
+ * with it on every shape and the host layer reaches it with algo = "winograd_vreg" / use_winograd4 = False. */
 size_t kmsr_conv3x3_winov_packed_weight_floats(int32_t Cin, int32_t Cout);
 int kmsr_conv3x3_winov_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int32_t Cin, int32_t Cout, float* packed,
                                         void* stream);
