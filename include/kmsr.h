@@ -202,6 +202,14 @@ int kmsr_pixel_unshuffle2_sum_f32(const float* g, int32_t N, int32_t C, int32_t 
  * per-tile weight reloads left them at a quarter of the HBM rate. */
 int kmsr_conv3x3_smallci_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* w, const float* bias, float* out,
                                  void* stream);
+/* The same kernel storing PIXEL-UNSHUFFLED (round 4): out is [N, 4 Cout, H/2, W/2] with out[n, 4 co + 2 (y & 1) + (x & 1), y >> 1, x >> 1] =
+ * conv(x, w)[n, co, y, x] (+ bias, ReLU), and chan_sums[4 Cout] receives sum_{n,y,x} of every output channel (fixed order).  It is the data
+ * gradient of the SR tail (bands -> F at HR size) delivered in the layout the F -> 4F + PixelShuffle(2) layer below takes as its output
+ * gradient, together with that layer's bias gradient: replaces kmsr_pixel_unshuffle2_sum_f32's extra pass over the HR-sized map.
+ * Cin <= 8, Cout <= 64, even H, W % 4 == 0.  workspace: kmsr_conv3x3_smallci_unshuffle_workspace_bytes(d). */
+size_t kmsr_conv3x3_smallci_unshuffle_workspace_bytes(const kmsr_conv3x3_desc* d);
+int kmsr_conv3x3_smallci_unshuffle_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* w, const float* bias, float* out,
+                                           float* chan_sums, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ============================================================================================
  * KernelGAN kernel composition (BASELINE config 5: batched per-patch kernel estimation).

@@ -82,6 +82,8 @@ SYMBOLS = {
     "kmsr_conv3x3_pixelshuffle_fwd_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp]),
     "kmsr_conv3x3_pixelshuffle_fwd_bf16": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp]),
     "kmsr_conv3x3_smallci_fwd_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp]),
+    "kmsr_conv3x3_smallci_unshuffle_workspace_bytes": (_sz, [C.POINTER(Conv3x3Desc)]),
+    "kmsr_conv3x3_smallci_unshuffle_fwd_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kmsr_conv3x3_wgrad_workspace_bytes": (_sz, [C.POINTER(Conv3x3Desc)]),
     "kmsr_conv3x3_wgrad_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _sz, _vp]),
     "kmsr_conv3x3_wino_packed_weight_floats": (_sz, [_i32, _i32]),

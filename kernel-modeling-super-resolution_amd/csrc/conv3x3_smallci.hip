@@ -33,10 +33,13 @@ struct SmallCiParams {
     int tiles_x, tiles, cgs, n_items, relu;
 };
 
-template <int CP2>      // channel pairs: Cin padded to 2 * CP2
+// UNSH (round 4): the output is stored PIXEL-UNSHUFFLED -- out[n, 4 co + 2 (y & 1) + (x & 1), y >> 1, x >> 1] -- and every lane keeps running
+// sums of what it stores per (row parity, channel): the data gradient of the SR tail then arrives in the layout the F -> 4F layer below
+// wants as its output gradient, with that layer's bias gradient, and no pass re-reads the HR-sized map (kmsr_conv3x3_smallci_unshuffle_fwd_f32).
+template <int CP2, bool UNSH>      // channel pairs: Cin padded to 2 * CP2
 __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __restrict__ xg, const float* __restrict__ wg,
                                                                  const float* __restrict__ bias, float* __restrict__ out,
-                                                                 SmallCiParams p) {
+                                                                 float* __restrict__ usum, SmallCiParams p) {
     constexpr int CP = 2 * CP2, TILE_F = CP * QPLANE;
     __shared__ __attribute__((aligned(16))) float lds[2 * TILE_F + 64];
     float* sbias = lds + 2 * TILE_F;
@@ -128,6 +131,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
     }
     store_stage(0);
     __syncthreads();
+    float cs[UNSH ? 2 : 1][2][16];                              // UNSH: running sums per (row parity, co block, register) of this lane's stores
+#pragma unroll
+    for (int a = 0; a < (UNSH ? 2 : 1); ++a)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs[a][cb][r] = 0.f;
     const int lbase = half * QPLANE + 3 + l32;                 // B operand: k = half picks the plane of the pair, pixel l32; + taps / group offsets
     for (; it < p.n_items; it += gridDim.x) {
         const int nxt = it + gridDim.x;
@@ -172,7 +182,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 const int x = x0 + 32 * ch + l32;
-                const unsigned vbase = (y < H && x < W) ? (unsigned)(y * W + x) * 4u : OOB;
+                const bool inimg = y < H && x < W;
+                unsigned vbase;
+                if constexpr (UNSH)     // the 4 sub-pixel planes of a channel occupy the channel's HW floats: same channel stride
+                    vbase = inimg ? (unsigned)((2 * (y & 1) + (x & 1)) * (int)(HW >> 2) + (y >> 1) * (W >> 1) + (x >> 1)) * 4u : OOB;
+                else
+                    vbase = inimg ? (unsigned)(y * W + x) * 4u : OOB;
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -181,6 +196,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
                         float v = acc[ch][cb][r];
                         if (p.relu) v = fmaxf(v, 0.f);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, vbase + (unsigned)col * HWb, 0, 0);
+                        if constexpr (UNSH) cs[gp][cb][r] += inimg ? v : 0.f;
                     }
             }
         }
@@ -196,6 +212,36 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
         __syncthreads();
         b ^= 1;
     }
+    if constexpr (UNSH) {       // per-lane partial sums [block][wave][lane][row parity][co block][register]; reduced in a fixed order by the kernel below
+        float* o = usum + ((long long)(blockIdx.x * 4 + wv) * 64 + lane) * 64;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4*>(o + a * 32 + cb * 16 + 4 * q) = f32x4{cs[a][cb][4 * q], cs[a][cb][4 * q + 1], cs[a][cb][4 * q + 2], cs[a][cb][4 * q + 3]};
+    }
+}
+
+// sums[4 co + 2 yp + xp] = sum over blocks, waves and the 16 lanes of (k half, column parity xp) of their partials (fixed order: bit-reproducible)
+__global__ void __launch_bounds__(256) smallci_unshuffle_sum_kernel(const float* __restrict__ usum, int nblocks, float* __restrict__ sums) {
+    const int k = blockIdx.x, co = k >> 2, yp = (k >> 1) & 1, xp = k & 1;
+    const int cb = co >> 5, c5 = co & 31, half = (c5 >> 2) & 1, r = (c5 & 3) + 4 * (c5 >> 3);
+    const int total = nblocks * 4 * 16;                       // (block, wave, lane of the class)
+    float a = 0.f;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int j = e & 15, bw = e >> 4, lane = half * 32 + 2 * j + xp;
+        a += usum[((long long)bw * 64 + lane) * 64 + yp * 32 + cb * 16 + r];
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[k] = red[0];
 }
 
 }  // namespace
@@ -228,11 +274,57 @@ extern "C" int kmsr_conv3x3_smallci_fwd_f32(const kmsr_conv3x3_desc* d, const fl
     const int grid = (int)std::min<long long>(items, 2ll * cus);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     switch ((d->Cin + 1) / 2) {
-        case 1: conv3x3_smallci_kernel<1><<<grid, 256, 0, stream>>>(x, w, bias, out, p); break;
-        case 2: conv3x3_smallci_kernel<2><<<grid, 256, 0, stream>>>(x, w, bias, out, p); break;
-        case 3: conv3x3_smallci_kernel<3><<<grid, 256, 0, stream>>>(x, w, bias, out, p); break;
-        default: conv3x3_smallci_kernel<4><<<grid, 256, 0, stream>>>(x, w, bias, out, p); break;
+        case 1: conv3x3_smallci_kernel<1, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+        case 2: conv3x3_smallci_kernel<2, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+        case 3: conv3x3_smallci_kernel<3, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+        default: conv3x3_smallci_kernel<4, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
     }
+    KMSR_HIP_CHECK(hipGetLastError());
+    return KMSR_OK;
+}
+
+static int smallci_grid(const kmsr_conv3x3_desc* d) {
+    const long long items = (long long)ceil_div(d->W, QTW) * ceil_div(d->H, QTH) * d->N;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    return (int)std::min<long long>(items, 2ll * cus);
+}
+
+extern "C" size_t kmsr_conv3x3_smallci_unshuffle_workspace_bytes(const kmsr_conv3x3_desc* d) {
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0) return 0;
+    return (size_t)smallci_grid(d) * 4 * 64 * 64 * sizeof(float);
+}
+
+extern "C" int kmsr_conv3x3_smallci_unshuffle_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* w, const float* bias,
+                                                      float* out, float* chan_sums, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!d) return fail(KMSR_E_BADARG, "null descriptor");
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return fail(KMSR_E_BADARG, "bad conv shape");
+    if (!x || !w || !out || !chan_sums || !workspace) return fail(KMSR_E_BADARG, "null tensor pointer");
+    if (d->stride != 1 || d->pixel_shuffle || d->flags) return fail(KMSR_E_UNSUPPORTED, "small-Cin conv: stride 1, no pixel_shuffle, no flags");
+    if (d->Cin > 8 || d->Cout > 64) return fail(KMSR_E_UNSUPPORTED, "small-Cin unshuffle conv serves Cin <= 8, Cout <= 64 (Cin=%d, Cout=%d)", d->Cin, d->Cout);
+    if (d->H % 2 || d->W % 4 || reinterpret_cast<uintptr_t>(x) % 16) return fail(KMSR_E_UNSUPPORTED, "small-Cin unshuffle conv needs even H, W %% 4 == 0 and a 16-byte aligned input");
+    if ((long long)d->H * d->W * 4 * 64 >= (1ll << 31)) return fail(KMSR_E_UNSUPPORTED, "small-Cin conv: H*W exceeds 2^23 pixels per plane");
+    if (workspace_bytes < kmsr_conv3x3_smallci_unshuffle_workspace_bytes(d)) return fail(KMSR_E_NOMEM, "small-Cin unshuffle conv: workspace too small");
+    SmallCiParams p{};
+    p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.relu = d->relu;
+    p.tiles_x = ceil_div(d->W, QTW);
+    p.tiles = p.tiles_x * ceil_div(d->H, QTH);
+    p.cgs = 1;
+    p.n_items = p.tiles * d->N;
+    const int grid = smallci_grid(d);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    float* ws = static_cast<float*>(workspace);
+    switch ((d->Cin + 1) / 2) {
+        case 1: conv3x3_smallci_kernel<1, true><<<grid, 256, 0, stream>>>(x, w, bias, out, ws, p); break;
+        case 2: conv3x3_smallci_kernel<2, true><<<grid, 256, 0, stream>>>(x, w, bias, out, ws, p); break;
+        case 3: conv3x3_smallci_kernel<3, true><<<grid, 256, 0, stream>>>(x, w, bias, out, ws, p); break;
+        default: conv3x3_smallci_kernel<4, true><<<grid, 256, 0, stream>>>(x, w, bias, out, ws, p); break;
+    }
+    KMSR_HIP_CHECK(hipGetLastError());
+    smallci_unshuffle_sum_kernel<<<4 * d->Cout, 256, 0, stream>>>(ws, grid, chan_sums);
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
 }

@@ -238,6 +238,30 @@ def pixel_unshuffle2_sum(g):
     return gu, part.view(-1, 4 * C).sum(dim=0)
 
 
+def conv3x3_smallci_unshuffle(x, w, bias=None):
+    """conv3x3(x [N,Cin<=8,H,W], w [Cout<=64,Cin,3,3]) stored pixel-unshuffled -> (y [N,4 Cout,H/2,W/2], per-channel sums [4 Cout]) in one
+    launch (kmsr_conv3x3_smallci_unshuffle_fwd_f32): y[n, 4 co + 2 (i & 1) + (j & 1), i >> 1, j >> 1] = conv(x, w)[n, co, i, j]."""
+    lib = L.load()
+    x = x.contiguous()
+    w = w.detach().to(torch.float32).contiguous()
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    d = L.Conv3x3Desc()
+    d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, Cin, H, W, Cout, 1
+    y = torch.empty((N, 4 * Cout, H // 2, W // 2), device=x.device, dtype=torch.float32)
+    sums = torch.empty(4 * Cout, device=x.device, dtype=torch.float32)
+    nbytes = lib.kmsr_conv3x3_smallci_unshuffle_workspace_bytes(d)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(lib.kmsr_conv3x3_smallci_unshuffle_fwd_f32(d, L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), L.ptr(sums), L.ptr(ws), nbytes,
+                                                           L.current_stream()))
+    return y, sums
+
+
+def smallci_unshuffle_eligible(cin, cout, H, W):
+    return cin <= 8 and 32 <= cout <= 64 and H % 2 == 0 and W % 4 == 0 and H * W * 4 * 64 < 2 ** 31
+
+
 def _grad_sum(g):
     """Per-channel sum of a gradient tensor: taken from the producing launch's epilogue (tag set by _tag_sum on exactly this
     tensor object and storage version) when there is one, else one reduction pass."""
@@ -319,6 +343,40 @@ class Conv3x3Function(torch.autograd.Function):
         if ctx.has_residual and ctx.needs_input_grad[4]:
             dres = g                                          # y = conv(x) + residual
         return dx, dw, db, None, dres, None
+
+
+class UpTailFunction(torch.autograd.Function):
+    """out = tail(PixelShuffle2(up(h))) -- the last upsampler conv (F -> 4F, PixelShuffle fused into its store) and the tail conv
+    (F -> bands) as ONE autograd node, so that the tail's data gradient can be written directly in the un-shuffled layout the up conv
+    takes as its output gradient (kmsr_conv3x3_smallci_unshuffle_fwd_f32, which also emits the up conv's bias gradient): the separate
+    pixel_unshuffle2_sum pass over the HR-sized gradient map (2 x 8.6 GB at config 3) disappears.  Same arithmetic as the two
+    Conv3x3Function nodes (the un-shuffle is a permutation; the bias-gradient sums are taken in a different, fixed order)."""
+
+    @staticmethod
+    def forward(ctx, h, w_up, b_up, w_tail, b_tail):
+        h = h.contiguous()
+        y2 = Conv3x3Function._run(h, w_up, b_up, False, None, True)
+        out = Conv3x3Function._run(y2, w_tail, b_tail, False)
+        ctx.save_for_backward(h, w_up, y2, w_tail)
+        ctx.has_bias = (b_up is not None, b_tail is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w_up, y2, w_tail = ctx.saved_tensors
+        g = g.contiguous()
+        db_tail = _grad_sum(g) if ctx.has_bias[1] and ctx.needs_input_grad[4] else None
+        dw_tail = conv3x3_wgrad(y2, g) if ctx.needs_input_grad[3] else None
+        # tail data gradient = conv3x3(g, w') with w'[ci,co,u,v] = w_tail[co,ci,2-u,2-v], stored un-shuffled + its channel sums
+        wt = w_tail.detach().flip(2, 3).transpose(0, 1).contiguous()
+        gu, s = conv3x3_smallci_unshuffle(g, wt)
+        db_up = s if ctx.has_bias[0] and ctx.needs_input_grad[2] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx, sx = Conv3x3Function._run(gu, w_up, None, False, flip=True, chan_sum=True)
+            _tag_sum(dx, sx)
+        dw_up = conv3x3_wgrad(h, gu) if ctx.needs_input_grad[1] else None
+        return dx, dw_up, db_up, dw_tail, db_tail
 
 
 class ResBlockFunction(torch.autograd.Function):
@@ -531,6 +589,11 @@ class SRNet(nn.Module):
         self._caches = {}
         self.use_winograd = True    # inference path: Winograd MFMA kernels for the F->F / F->4F convs
         self.use_winograd4 = True   # inference path: F(4x4,3x3) for the aligned F->F / F->4F layers; False = F(2x2,3x3)
+        # training path: last upsampler conv + tail as one autograd node (UpTailFunction: the tail's data gradient is stored un-shuffled, no
+        # pixel_unshuffle2_sum pass).  OFF: correct (bit-identical gradients) and 2.5 ms SLOWER per config-3 step (91.1 vs 88.6 ms, A/B in one
+        # process, tools/time_train_ab.py) -- the un-shuffled store splits every 128-byte line of the 8.6 GB map into two 64-byte halves written by
+        # different instructions, which costs more than the separate pass saves.
+        self.fuse_up_tail_backward = False
         self.fuse_upsampler = True   # inference path, x4 only: up1/PS/up2/PS/tail (linear) run as one 5x5 conv + PS4 + the border-class frame launch
         #                              (same outputs, tests/test_fullsize_gpu.py; False = three conv3x3 launches)
         self._fused_up = _FusedUpsampler()
@@ -567,8 +630,13 @@ class SRNet(nn.Module):
         for blk in self.body:
             h = ResBlockFunction.apply(h, blk.conv1.weight, blk.conv1.bias, blk.conv2.weight, blk.conv2.bias)
         h = cv(self.body_tail, h, residual=f)
-        for up in self.up:
+        ups = list(self.up)
+        fuse = bool(ups) and self.fuse_up_tail_backward and smallci_unshuffle_eligible(self.n_colors, self.n_feats, 2 * h.shape[-2] * 2 ** (len(ups) - 1),
+                                                                                       2 * h.shape[-1] * 2 ** (len(ups) - 1))
+        for up in (ups[:-1] if fuse else ups):
             h = cv(up, h, ps=True)
+        if fuse:        # last upsampler conv + tail as one node: the tail's data gradient is written un-shuffled (UpTailFunction)
+            return UpTailFunction.apply(h, ups[-1].weight, ups[-1].bias, self.tail.weight, self.tail.bias)
         return cv(self.tail, h)
 
     def _forward_infer(self, x):

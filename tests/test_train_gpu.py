@@ -126,3 +126,44 @@ def test_pixel_unshuffle2_sum_vs_torch(N, C, H, W, gpu_device):
     assert float((s.double() - want).abs().max()) <= 2e-6 * float(ref.abs().double().sum(dim=(0, 2, 3)).max())
     gu2, s2 = pixel_unshuffle2_sum(g)
     assert torch.equal(s, s2)
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout", [(2, 5, 16, 64, 64), (1, 3, 34, 132, 64), (3, 7, 8, 8, 48), (1, 5, 64, 256, 64)])
+def test_smallci_unshuffle_equals_conv_then_unshuffle(N, Cin, H, W, Cout, gpu_device):
+    """kmsr_conv3x3_smallci_unshuffle_fwd_f32: the small-Cin conv stored pixel-unshuffled is BIT-IDENTICAL to the same kernel's normal
+    output passed through pixel_unshuffle(2), and its channel sums match a float64 reduction (ragged tiles, several images, Cout < 64)."""
+    from kmsr_amd.sr import conv3x3_smallci_unshuffle
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 5).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    want = torch.nn.functional.pixel_unshuffle(conv3x3(x, w, Cout, bias=b, algo="smallci"), 2)
+    got, sums = conv3x3_smallci_unshuffle(x, w, bias=b)
+    assert got.shape == want.shape and torch.equal(got, want)
+    ref = want.double().sum(dim=(0, 2, 3))
+    assert float((sums.double() - ref).abs().max()) <= 2e-6 * float(want.double().abs().sum(dim=(0, 2, 3)).max() + 1)
+    assert torch.equal(conv3x3_smallci_unshuffle(x, w, bias=b)[1], sums)          # fixed-order reduction: run-to-run identical
+
+
+def test_up_tail_node_matches_separate_nodes(gpu_device):
+    """SRNet's training graph with the last upsampler conv + tail as ONE node (tail data gradient written un-shuffled, no
+    pixel_unshuffle2_sum pass) against the graph of separate Conv3x3Function nodes: same loss, gradients equal within fp32 rounding
+    of the bias-gradient sums (data / weight gradients bit-identical: the same kernels on a permuted store)."""
+    torch.manual_seed(5)
+    net = SRNet(5, 64, 2, 4).cuda().train()
+    x = torch.rand(2, 5, 16, 32, device="cuda") * 80 + 20
+    tgt = torch.rand(2, 5, 64, 128, device="cuda") * 80 + 20
+    grads = []
+    for fuse in (True, False):
+        net.fuse_up_tail_backward = fuse
+        net.zero_grad()
+        loss = F.l1_loss(net(x), tgt)
+        loss.backward()
+        grads.append((float(loss), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    assert grads[0][0] == grads[1][0]
+    for k in grads[0][1]:
+        a, b = grads[0][1][k], grads[1][1][k]
+        if k.endswith("weight") or not k.startswith("up.1"):
+            assert torch.equal(a, b), k
+        else:
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max() + 1e-30), k
