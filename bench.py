@@ -347,8 +347,9 @@ class DegradeSRWorkload:
             with torch.no_grad():
                 return ref(torch.from_numpy(lr))
 
-        def rate(fn, budget, nmax):
-            fn()
+        def rate(fn, budget, nmax, warm=1):
+            for _ in range(warm):
+                fn()
             t0 = time.perf_counter()
             n = 0
             while True:
@@ -363,7 +364,7 @@ class DegradeSRWorkload:
             torch.set_num_threads(n)
 
         threads(cores)
-        v_all, n_all, el_all = rate(one, budget_s, 16)
+        v_all, n_all, el_all = rate(one, 2 * budget_s, 20, warm=3)          # 3 warm-ups, 20 timed iterations (~0.45 s each on 16 threads)
         hr_t, kern_t = torch.from_numpy(hr), torch.from_numpy(kern)
         deg = {"unit": "LR patches/s", "shape": "HR 3x1024x1024 -> LR 3x256x256 (clean V-B part, no noise)"}
         deg["oracle_c_all_cores"] = round(rate(lambda: oracle.vb_blur_stride(hr, kern, 4), 1.0, 200)[0], 2)
@@ -395,7 +396,7 @@ class DegradeSRWorkload:
                            "max_rel_diff": float((sr_gpu - sr_cpu).abs().max() / sr_cpu.abs().max())}
         self.net.fuse_upsampler = True
         return {"value": round(v_all, 3), "unit": "LR patches/s", "cores": cores, "kind": "port",
-                "sample": f"{n_all} patch(es): HR 3x1024x1024 -> LR 256^2 -> SR 1024^2, oracle C degradation + torch-CPU "
+                "sample": f"{n_all} timed patch(es) after 3 warm-ups: HR 3x1024x1024 -> LR 256^2 -> SR 1024^2, oracle C degradation + torch-CPU "
                           f"SRNetTorch fp32, {el_all:.1f} s on {cores} threads",
                 "one_thread": {"value": round(v_one, 4), "cores": 1, "sample": "median of 3 timed calls (1 warm-up) of the same 1-patch step, OMP / ATen threads = 1",
                                "calls_s": [round(t, 3) for t in t_one]},
