@@ -151,3 +151,21 @@ def test_degradation_model(gpu_device):
     assert_close(sigma.cpu().numpy(), KG["muti__noise_sigma"], rtol=1e-6, what="sigma")
     want = oracle.add_gaussian_noise(clean.cpu().numpy(), np.tile(sigma.cpu().numpy(), 2), seed=11, offset=0)
     assert_close(noisy.cpu().numpy(), want, rtol=1e-6, atol=2e-6, what="noisy")
+
+
+def test_flat_weight_cache_follows_parameter_updates(gpu_device):
+    """The composition kernel's flat weight operand is built once and reused (round 4: no torch.cat per call); an in-place parameter update
+    (an optimizer step bumps the version counter) or load_state_dict must invalidate it."""
+    torch.manual_seed(11)
+    for gen, args in ((kmsr_amd.DynamicMultiBandLinearGenerator().cuda(), (None,)), (kmsr_amd.MultiBandLinearGenerator(in_ch=5, mid_ch=32).cuda(), ())):
+        k0 = gen.extract_effective_kernels(*args).clone()
+        flat0 = gen._flat_cache[1]
+        assert gen.extract_effective_kernels(*args) is not None and gen._flat_cache[1] is flat0          # second call: the same buffer
+        w = next(gen.parameters())
+        with torch.no_grad():
+            w.mul_(1.5)
+        k1 = gen.extract_effective_kernels(*args)
+        assert gen._flat_cache[1] is not flat0 and not torch.equal(k0, k1)
+        ref = type(gen)().cuda() if args else type(gen)(in_ch=5, mid_ch=32).cuda()
+        ref.load_state_dict(gen.state_dict())
+        assert torch.equal(ref.extract_effective_kernels(*args), k1)
