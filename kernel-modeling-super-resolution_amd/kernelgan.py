@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .sr import Conv3x3Function, conv3x3, pack_for, pick_algo
+from .sr import Conv3x3Function, Conv3x3S2Function, conv3x3, pack_for, pick_algo
 
 KS = (7, 5, 3, 1, 1, 1)
 
@@ -224,15 +224,15 @@ class ConditionEncoder(nn.Module):
 
     def scales_tensor(self, x):
         """[B, in_ch, 161]: for every band the 6 layers' scales concatenated (the reference returns the same numbers
-        as a list[band][layer] of [B,out_c] tensors, :46-58).  Under autograd the convs are Conv3x3Function nodes (HIP
-        forward / dgrad / wgrad; a stride-2 pad-1 conv is the stride-1 conv sampled at even positions)."""
+        as a list[band][layer] of [B,out_c] tensors, :46-58).  Under autograd the convs are Conv3x3Function / Conv3x3S2Function nodes
+        (HIP forward / dgrad / wgrad; the stride-2 layers at the minimum work since round 4)."""
         if torch.is_grad_enabled():
             h = x.detach()
             for conv in (self.encoder[0], self.encoder[2], self.encoder[4]):
                 if conv.stride[0] == 1:
                     h = Conv3x3Function.apply(h, conv.weight, conv.bias, True)
-                else:
-                    h = torch.relu(Conv3x3Function.apply(h, conv.weight, conv.bias, False)[:, :, ::2, ::2])
+                else:       # stride 2: native forward / data gradient / weight gradient (sr.Conv3x3S2Function, round 4)
+                    h = torch.relu(Conv3x3S2Function.apply(h, conv.weight, conv.bias))
         else:
             h = x
             for conv, algo, pw in self._packs(x.shape[-1]):

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from . import _lib as L
 from . import dist as kd
 from .degradation import DegradeFunction, degrade_batch
-from .sr import Conv3x3Function, conv3x3, pack_conv3x3_weight
+from .sr import Conv3x3Function, Conv3x3S2Function, conv3x3, pack_conv3x3_weight
 
 
 class SelectorNet(nn.Module):
@@ -63,13 +63,14 @@ class SelectorNet(nn.Module):
             return self._forward_infer(x)
 
     def _forward_train(self, x):
-        """Differentiable path, BatchNorm as the module's mode says (batch statistics in train()).  A stride-2 pad-1
-        conv equals the stride-1 conv sampled at even positions, so the stride-1 HIP forward / dgrad / wgrad kernels
-        serve it (4x the minimum work on a net that is ~1 % of a step)."""
+        """Differentiable path, BatchNorm as the module's mode says (batch statistics in train()).  The stride-2 convs run
+        natively in both directions (Conv3x3S2Function, round 4: the stride-2 forward kernel; data / weight gradients as stride-1
+        problems in pixel-(un)shuffled coordinates on the F(4x4,3x3) kernels) -- until round 3 the stride-1 conv was computed and
+        three quarters of it discarded, forward and backward."""
         h = x
         for ci, bi in ((0, 1), (3, 4), (6, 7)):
             conv, bn = self.features[ci], self.features[bi]
-            h = Conv3x3Function.apply(h, conv.weight, conv.bias, False)[:, :, ::2, ::2]
+            h = Conv3x3S2Function.apply(h, conv.weight, conv.bias)
             h = F.relu(bn(h))
         feat = h.mean(dim=(2, 3))
         return self.classifier(feat)

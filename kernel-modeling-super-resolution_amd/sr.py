@@ -345,6 +345,75 @@ class Conv3x3Function(torch.autograd.Function):
         return dx, dw, db, None, dres, None
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# Stride-2 conv3x3 (pad 1) with a backward at the MINIMUM work (round 4; the selector / condition-encoder nets of the reference's trainers,
+# train_gemini.py:18-31, muti_kernel/networks.py:21-33).  Until round 3 the training path ran the stride-1 conv and kept every second
+# pixel: 4x the work in forward, data gradient and weight gradient.  Both gradients are stride-1 problems in pixel-(un)shuffled
+# coordinates, so the existing stride-1 kernels serve them exactly:
+#   y[i, j]       = sum_{u,v} w[u, v] x[2i + u - 1, 2j + v - 1]
+#   dx[2I + a, .] = sum over (a, s) -> u in {(0,1)->1, (1,1)->2, (1,2)->0} of w[u, .] g[I + s - 1, .]
+#                 = PixelShuffle2( conv3x3_stride1(g, W') ),  W'[4 ci + 2a + b, co, s, t] = w[co, ci, u(a,s), v(b,t)]  (other taps zero)
+#                   -> ONE launch of the F(4x4,3x3) Winograd kernel with its fused PixelShuffle store: 9 products per LR pixel and
+#                      (co, ci) pair, the minimum;
+#   dw[co,ci,u,v] = sum g[co,i,j] x[ci, 2i + u - 1, 2j + v - 1] = dw1[co, 4 ci + 2a + b, s, t] with u -> (a, s) in {0->(1,0), 1->(0,1), 2->(1,1)},
+#                   dw1 = the stride-1 weight gradient between xu = PixelUnshuffle2(x) and g (F(4x4,3x3) domain where eligible).
+def s2_dgrad_weights(w):
+    """w [Cout,Cin,3,3] of a stride-2 conv -> W' [4 Cin, Cout, 3, 3]: dx = pixel_shuffle(conv2d(g, W', padding=1), 2)[..., :H, :W]."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    wp = w.new_zeros((Cin, 2, 2, Cout, 3, 3))
+    umap = {(0, 1): 1, (1, 1): 2, (1, 2): 0}
+    for (a, s_), u in umap.items():
+        for (b, t_), v in umap.items():
+            wp[:, a, b, :, s_, t_] = w[:, :, u, v].transpose(0, 1)
+    return wp.reshape(4 * Cin, Cout, 3, 3)
+
+
+def s2_wgrad_gather(dw1, cin):
+    """dw1 [Cout, 4 Cin, 3, 3] = stride-1 weight gradient between pixel_unshuffle(x, 2) and g -> dw [Cout, Cin, 3, 3] of the stride-2 conv."""
+    cout = dw1.shape[0]
+    d = dw1.reshape(cout, cin, 2, 2, 3, 3)
+    amap = {0: (1, 0), 1: (0, 1), 2: (1, 1)}                 # u -> (phase a, tap s)
+    dw = dw1.new_empty((cout, cin, 3, 3))
+    for u, (a, s_) in amap.items():
+        for v, (b, t_) in amap.items():
+            dw[:, :, u, v] = d[:, :, a, b, s_, t_]
+    return dw
+
+
+class Conv3x3S2Function(torch.autograd.Function):
+    """y = conv3x3(x, w, stride 2, padding 1) + b on the HIP kernels in both directions: forward kmsr_conv3x3_fwd_f32 (stride 2), data
+    gradient = one F(4x4,3x3) launch with the fused PixelShuffle store on re-indexed weights, weight gradient = the stride-1 kernel on
+    the pixel-unshuffled input (see the block comment above).  ReLU / BatchNorm stay with the caller."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        y = conv3x3(x, _TrainPacks.get(weight, "direct", False), weight.shape[0], bias=bias, stride=2, algo="direct")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        N, Cin, H, W = x.shape
+        Cout, Ho, Wo = w.shape[0], g.shape[2], g.shape[3]
+        dx = dw = db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g.sum(dim=(0, 2, 3))
+        if ctx.needs_input_grad[0]:
+            wp = s2_dgrad_weights(w.detach())
+            algo = pick_algo(Cout, 4 * Cin, 1, Wo, Conv3x3Function.use_winograd, f4=Conv3x3Function.use_winograd4)
+            dxf = conv3x3(g, pack_for(algo, wp), 4 * Cin, pixel_shuffle=True, algo=algo)          # [N, Cin, 2 Ho, 2 Wo]
+            dx = dxf if (2 * Ho, 2 * Wo) == (H, W) else dxf[:, :, :H, :W].contiguous()
+        if ctx.needs_input_grad[1]:
+            xe = x if (2 * Ho, 2 * Wo) == (H, W) else torch.nn.functional.pad(x, (0, 2 * Wo - W, 0, 2 * Ho - H))
+            xu = torch.nn.functional.pixel_unshuffle(xe, 2).contiguous()                            # [N, 4 Cin, Ho, Wo]
+            dw = s2_wgrad_gather(conv3x3_wgrad(xu, g), Cin)
+        return dx, dw, db
+
+
 class UpTailFunction(torch.autograd.Function):
     """out = tail(PixelShuffle2(up(h))) -- the last upsampler conv (F -> 4F, PixelShuffle fused into its store) and the tail conv
     (F -> bands) as ONE autograd node, so that the tail's data gradient can be written directly in the un-shuffled layout the up conv

@@ -303,3 +303,25 @@ def test_make_golden_reproduces_fixtures(tmp_path):
         assert sorted(a.files) == sorted(b.files), f
         for k in a.files:
             assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), f"{f}:{k} differs"
+
+
+def test_stride2_backward_index_maps_cpu():
+    """Host logic of sr.Conv3x3S2Function (round 4), checked with stock torch on the CPU: the data gradient of a stride-2 pad-1 conv is
+    PixelShuffle2 of a stride-1 conv of the output gradient with the re-indexed weights s2_dgrad_weights(w), and its weight gradient is a
+    gather (s2_wgrad_gather) from the stride-1 weight gradient between PixelUnshuffle2(x) and the output gradient -- odd and even sizes."""
+    import torch
+    import torch.nn.functional as F
+    from kmsr_amd.sr import s2_dgrad_weights, s2_wgrad_gather
+    torch.manual_seed(0)
+    for (N, Cin, H, W, Cout) in [(2, 3, 8, 12, 5), (1, 4, 9, 7, 6), (2, 2, 5, 5, 3), (1, 1, 2, 2, 1)]:
+        x = torch.randn(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x, w, stride=2, padding=1)
+        g = torch.randn_like(y)
+        y.backward(g)
+        Ho, Wo = y.shape[2:]
+        dx = F.pixel_shuffle(F.conv2d(g, s2_dgrad_weights(w.detach()), padding=1), 2)[:, :, :H, :W]
+        xu = F.pixel_unshuffle(F.pad(x.detach(), (0, 2 * Wo - W, 0, 2 * Ho - H)), 2)
+        w1 = torch.zeros(Cout, 4 * Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xu, w1, padding=1).backward(g)
+        assert float((dx - x.grad).abs().max()) < 1e-12 and float((s2_wgrad_gather(w1.grad, Cin) - w.grad).abs().max()) < 1e-12

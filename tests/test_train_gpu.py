@@ -167,3 +167,24 @@ def test_up_tail_node_matches_separate_nodes(gpu_device):
             assert torch.equal(a, b), k
         else:
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max() + 1e-30), k
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout", [(2, 5, 64, 64, 32), (2, 32, 32, 32, 64), (1, 64, 16, 24, 128), (1, 32, 17, 30, 64), (3, 5, 9, 9, 32)])
+def test_conv3x3_stride2_function_vs_torch(N, Cin, H, W, Cout, gpu_device):
+    """sr.Conv3x3S2Function (stride-2 forward kernel; data gradient = one F(4x4) / direct launch with the fused PixelShuffle store on
+    re-indexed weights; weight gradient = the stride-1 kernels on the pixel-unshuffled input) against torch autograd in float64: the
+    SelectorNet / ConditionEncoder shapes, odd sizes (cropped data gradient, padded un-shuffle), widths that are not multiples of 8."""
+    from kmsr_amd.sr import Conv3x3S2Function
+    g = torch.Generator().manual_seed(Cin + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = (t.clone().double().requires_grad_() for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, stride=2, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+    xc, wc, bc = (t.clone().cuda().requires_grad_() for t in (x, w, b))
+    yc = Conv3x3S2Function.apply(xc, wc, bc)
+    yc.backward(gy.cuda())
+    assert yc.shape == yr.shape and _rel(yc, yr) < 2e-5
+    assert _rel(xc.grad, xr.grad) < 2e-5 and _rel(wc.grad, wr.grad) < 2e-5 and _rel(bc.grad, br.grad) < 2e-5
