@@ -33,7 +33,9 @@ NOLDS = [("        if (k & 1) P.e[k >> 1] = f32x2{rp[0], rp[5]};\n        else P
          ("        D.g[r] = *reinterpret_cast<const f32x4*>(st + dbase + a * HDCH + 16 * ks + r * HDROW);", "        if (p.N == 12345) D.g[r] = *reinterpret_cast<const f32x4*>(st + dbase + a * HDCH + 16 * ks + r * HDROW); else D.g[r] = f32x4{1.f, 2.f, 3.f, 4.f};")]
 NOFLUSH = [("    flush(acc, first_flush);", "    if (p.N == 12345 || s1 == s_end) flush(acc, first_flush);")]
 DMAHALF = [("        if (di >= 0) dma_issue(di, nb); ", "        if (di >= 0 && (di & 1) == 0) dma_issue(di, nb); ")]
-ABL = {"dmahalf": DMAHALF, "nodma": NODMA, "dmal2": DMAL2, "nomfma": NOMFMA, "novalu": NOVALU, "nobar": NOBAR, "nolds": NOLDS, "noflush": NOFLUSH,
+def lag(n):   # the second channel group of a stream starts n x 64 cycles late: its dy requests become true L2 hits instead of hits-on-miss
+    return [("    // ---- prologue: stage s_beg -> buffer 0", "    if (grp & 1) __builtin_amdgcn_s_sleep(%d);\n    // ---- prologue: stage s_beg -> buffer 0" % n)]
+ABL = {"lag32": lag(32), "lag64": lag(64), "lag127": lag(127), "dmahalf": DMAHALF, "nodma": NODMA, "dmal2": DMAL2, "nomfma": NOMFMA, "novalu": NOVALU, "nobar": NOBAR, "nolds": NOLDS, "noflush": NOFLUSH,
        "mfmaonly": NODMA + NOVALU + NOBAR + NOLDS, "nodma_nolds": NODMA + NOLDS, "nolds_novalu": NOLDS + NOVALU, "nodma_novalu": NODMA + NOVALU}
 for n in (sys.argv[1:] or ABL):
     build(n, ABL[n])
