@@ -62,12 +62,12 @@ __device__ __forceinline__ unsigned relu_pk(unsigned u) {                     //
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, u), i16x2_t{0, 0}));
 }
 // Nothing may move across the end of an MFMA phase, and the phase drains before the epilogue's first VALU instruction.  Two reasons:
-// (1) the inline-asm MFMAs are invisible to the hazard recognizer (result -> VALU read needs the 8 passes);
-// (2) observed on gfx950: a VALU write to a register that an MFMA issued a few cycles earlier reads as SrcB corrupts that product.
-//     hipcc (which models MFMA sources as read at issue) scheduled `v_accvgpr_read v94, ...` 8 cycles behind
-//     `v_mfma_f32_32x32x16_bf16 ..., v[94:97], ...` once the epilogue was written with packed operations, and elements (g = 0,
-//     pairs 0 / 1) of half the tiles came out wrong -- in SOME runs of the same binary, with the BUILTIN MFMAs too
-//     (tools/diag/dbg_rb.py; profiles/r04_mfma_srcb_war.log).
+// (1) the inline-asm MFMAs are invisible to the hazard recognizer (result -> VALU read needs the MFMA's passes);
+// (2) observed on gfx950 with the BUILTIN MFMAs too: once the epilogue was written with packed operations hipcc scheduled its first
+//     instructions between the last MFMAs of the phase (`v_accvgpr_read v94, a32` 8 cycles behind `v_mfma ..., v[94:97], ...`, next to
+//     accumulator reads of a tile whose last MFMA had issued three instructions earlier), and accumulator registers 0 / 1 of half the
+//     tiles came out wrong -- in SOME runs of the same binary (tools/diag/dbg_rb.py).  Whether the SrcB overwrite or a too-short wait
+//     before the accumulator read is the cause was not isolated; the fence removes both.
 #define RB_DRAIN()                                                                        \
     {                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                \

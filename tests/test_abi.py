@@ -278,12 +278,11 @@ def test_no_wide_store_with_sgpr_soffset():
 
 
 def test_mfma_sources_are_not_overwritten_right_behind_the_mfma():
-    """Round 4: on gfx950 a VALU write to a register that an MFMA issued a few cycles earlier reads as SrcA / SrcB
-    corrupted the product intermittently (v_mfma_f32_32x32x16_bf16 fetches its operands after issue; hipcc models them as read at
-    issue and scheduled `v_accvgpr_read v94` 8 cycles behind `v_mfma ..., v[94:97], ...`).  The kernels that recycle operand registers
-    right after an MFMA phase fence it (RB_DRAIN in resblock_bf16.hip; the weight-gradient kernel keeps its operands pinned through
-    the phase): compile them and check that no VALU / AGPR-read instruction writes an MFMA's source VGPRs within the next 8
-    vector instructions unless >= 32 cycles of s_nop lie between."""
+    """Round 4: with epilogue VALU work scheduled into the tail of its MFMA phase -- among it a write to a register an
+    in-flight v_mfma_f32_32x32x16_bf16 reads as SrcB -- the fused res-block kernel produced wrong accumulator registers in SOME runs of the same
+    binary; the cause was not isolated, the kernel now fences its MFMA phases (RB_DRAIN).  This guard keeps the scheduled-into-the-tail pattern
+    out: compile the kernel and check that no VALU / AGPR-read instruction writes an MFMA's source VGPRs within the next 8 vector instructions
+    unless >= 32 cycles of s_nop lie between."""
     import re
     import shutil
     import subprocess
