@@ -61,17 +61,18 @@ typedef short i16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned relu_pk(unsigned u) {                     // ReLU of a packed bf16 pair: v_pk_max_i16 with 0
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, u), i16x2_t{0, 0}));
 }
-// Nothing may move across the end of an MFMA phase, and the phase drains before the epilogue's first VALU instruction.  Two reasons:
-// (1) the inline-asm MFMAs are invisible to the hazard recognizer (result -> VALU read needs the MFMA's passes);
-// (2) observed on gfx950 with the BUILTIN MFMAs too: once the epilogue was written with packed operations hipcc scheduled its first
-//     instructions between the last MFMAs of the phase (`v_accvgpr_read v94, a32` 8 cycles behind `v_mfma ..., v[94:97], ...`, next to
-//     accumulator reads of a tile whose last MFMA had issued three instructions earlier), and accumulator registers 0 / 1 of half the
-//     tiles came out wrong -- in SOME runs of the same binary (tools/diag/dbg_rb.py).  Whether the SrcB overwrite or a too-short wait
-//     before the accumulator read is the cause was not isolated; the fence removes both.
+// Nothing may move across the end of an MFMA phase, and the phase drains before the epilogue's first VALU instruction: a VALU read of a
+// v_mfma_f32_32x32x16_bf16 result is NOT interlocked on gfx950 -- it returns the old register contents until 11 wait states after the MFMA
+// issued (tools/ubench/mfma_bf16_hazards.hip, profiles/r04_ubench_mfma_bf16_hazards.log: s_nop 9 fails on every lane, s_nop 10 passes 1.5e9
+// checks).  hipcc's hazard recognizer inserts exactly those 11 for the builtin, but the inline-asm MFMAs here are invisible to it, and once the
+// epilogue was written with packed operations the scheduler moved its first accumulator reads up between the last MFMAs of the phase: accumulator
+// registers 0 / 1 of half the tiles came out wrong in some runs (tools/diag/dbg_rb.py).  The other suspects were measured innocent by the same
+// microbenchmark: a VALU write to SrcB right behind the MFMA, and VALU writes to SrcC / SrcB right in front of it, never change the result
+// (DESIGN 4.12 fact 11).  The fence = no reordering across it + 12 wait states.
 #define RB_DRAIN()                                                                        \
     {                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                \
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");        \
+        asm volatile("s_nop 11" ::: "memory");                                            \
         __builtin_amdgcn_sched_barrier(0);                                                \
     }
 // v_mfma_f32_32x32x16_bf16 with explicit register classes: accumulator in VGPRs, weight operand IDX (0 .. 71 over both layers) in AGPRs
