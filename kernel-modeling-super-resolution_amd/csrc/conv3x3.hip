@@ -11,6 +11,10 @@
 // 8 x 10 x 34 + the chunk's 9 x 8 x 64 weights = 30 KB), double buffered: the next chunk's global loads are
 // issued before the current chunk's 144 MFMAs per wave and written to the other buffer after them, one
 // __syncthreads per chunk.  Two blocks per CU (2 waves per SIMD) overlap one block's barrier with the other's MFMAs.
+// The stride-2 instance stages 4 channels per chunk (8 x 17 x 68 floats would be 110 KB double buffered = ONE block per CU, whose first-chunk
+// load latency and 64-stores-per-lane epilogue nothing covers: 0.40 of the fp32 pipe at Cin = 32, round 4); its chunks are half chunks of
+// the same packed weight layout.  Input loads are buffer loads: padding positions and the channels past Cin carry an out-of-range offset and
+// come back as zeros, so a load costs no VALU instruction (the select / 64-bit address pairs were 200 of 330 VALU per chunk next to 144 MFMAs).
 #include "kmsr_common.h"
 
 #include <algorithm>
@@ -18,7 +22,7 @@
 namespace kmsr {
 namespace {
 
-constexpr int CK = 8;     // input channels per LDS chunk
+constexpr int CK = 8;     // input channels per chunk of the PACKED weight layout (and per LDS chunk of the stride-1 instances)
 constexpr int TH = 8;     // output tile rows per block
 constexpr int TW = 32;    // output tile cols per block (= MFMA N)
 constexpr int COB = 64;   // output channels per block (2 MFMA M blocks)
@@ -44,12 +48,14 @@ struct ConvCfg {
     static constexpr int IH = (TH - 1) * S + 3;
     static constexpr int IW = (TW - 1) * S + 3;
     static constexpr int IWP = (IW + 3) / 4 * 4;
-    static constexpr int IN_FLOATS = CK * IH * IWP;
-    static constexpr int W_FLOATS = 9 * CK * COB;
+    static constexpr int CKC = S == 2 ? 4 : CK;                // input channels per LDS chunk; CK / CKC kernel chunks per packed chunk
+    static constexpr int IN_FLOATS = CKC * IH * IWP;
+    static constexpr int W_FLOATS = 9 * CKC * COB;
     static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
-    static constexpr int IN_ELEMS = CK * IH * IW;
+    static constexpr int IN_ELEMS = CKC * IH * IW;
     static constexpr int NIN = (IN_ELEMS + 255) / 256;
     static constexpr int NW4 = (W_FLOATS / 4 + 255) / 256;
+    static constexpr int PACKED_CHUNK_FLOATS = 9 * CK * COB;
 };
 
 // packed[cg][chunk][tap][c][co]  <-  w[co_g][ci_g][tap]   (zero padded); transpose_flip: data-gradient weights
@@ -74,13 +80,13 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Cin, int Co
 }
 
 template <int S, bool PS>
-__global__ void __launch_bounds__(256, S == 1 ? 2 : 1) conv3x3_mfma_kernel(const float* __restrict__ xg, const float* __restrict__ wpk,
+__global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __restrict__ xg, const float* __restrict__ wpk,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ res, float* __restrict__ out,
                                                               ConvParams p) {
     using Cfg = ConvCfg<S>;
     constexpr int IH = Cfg::IH, IW = Cfg::IW, IWP = Cfg::IWP, IN_FLOATS = Cfg::IN_FLOATS, W_FLOATS = Cfg::W_FLOATS;
-    constexpr int BUF = Cfg::BUF_FLOATS, IN_ELEMS = Cfg::IN_ELEMS, NIN = Cfg::NIN, NW4 = Cfg::NW4;
+    constexpr int BUF = Cfg::BUF_FLOATS, IN_ELEMS = Cfg::IN_ELEMS, NIN = Cfg::NIN, NW4 = Cfg::NW4, CKC = Cfg::CKC;
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
     const int tid = threadIdx.x;
@@ -99,18 +105,19 @@ __global__ void __launch_bounds__(256, S == 1 ? 2 : 1) conv3x3_mfma_kernel(const
     const int H = p.H, W = p.W;
     const long long HW = (long long)H * W;
 
-    // ---- staging map of the input halo tile (same for every chunk)
-    int goff[NIN];
+    // ---- staging map of the input halo tile (same for every chunk): BYTE offsets from the chunk's first channel plane; zero padding and
+    //      the slots past the tile get an offset no buffer covers (the host checks CK * H * W * 4 < 2^32)
+    unsigned goff[NIN];
 #pragma unroll
     for (int t = 0; t < NIN; ++t) {
         const int e = tid + 256 * t;
         const int c = e / (IH * IW), rem = e - c * (IH * IW), r = rem / IW, col = rem - r * IW;
         const int gy = ty0 * S - 1 + r, gx = tx0 * S - 1 + col;
         const bool ok = e < IN_ELEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        goff[t] = ok ? (int)(c * HW + (long long)gy * W + gx) : -1;
+        goff[t] = ok ? (unsigned)(c * HW + (long long)gy * W + gx) * 4u : 0xFFFFFFFFu;
     }
     const float* __restrict__ xn = xg + (long long)n * p.Cin * HW;
-    const float* __restrict__ wcg = wpk + (long long)cg * p.nchunks * W_FLOATS;
+    const float* __restrict__ wcg = wpk + (long long)cg * p.nchunks * Cfg::PACKED_CHUNK_FLOATS;
 
     // One register staging set: the next chunk's global loads are ISSUED after the first tap's MFMAs (their ~80
     // address/load instructions then issue in the shadow of the matrix pipe instead of ahead of it) and are written
@@ -118,20 +125,19 @@ __global__ void __launch_bounds__(256, S == 1 ? 2 : 1) conv3x3_mfma_kernel(const
     float xinA[NIN];
     f32x4 wregA[NW4];
     auto load_chunk = [&](int chunk, float (&xin)[NIN], f32x4 (&wreg)[NW4]) {
-        const float* __restrict__ xc = xn + (long long)chunk * CK * HW;
-        const int cin_left = p.Cin - chunk * CK;
+        // the buffer = what is left of this image from the chunk's first channel: channels past Cin are out of range too (channel padding)
+        const long long left = ((long long)p.Cin - (long long)chunk * CKC) * HW * 4;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(xn + (long long)chunk * CKC * HW), 0, (unsigned)(left < 0xFFFFFFFFll ? left : 0xFFFFFFFFll), 0x00020000);
 #pragma unroll
-        for (int t = 0; t < NIN; ++t) {
-            const int c = (tid + 256 * t) / (IH * IW);
-            const bool ok = goff[t] >= 0 && c < cin_left;
-            const float v = xc[ok ? goff[t] : 0];   // unconditional load from a safe address + select: no branch, no
-            xin[t] = ok ? v : 0.f;                  // per-load wait (zero padding and channel padding come from here)
-        }
-        const f32x4* __restrict__ wc = reinterpret_cast<const f32x4*>(wcg + (long long)chunk * W_FLOATS);
+        for (int t = 0; t < NIN; ++t) xin[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, goff[t], 0, 0));
+        // kernel chunk -> (packed chunk, part): per tap the part's CKC x COB floats are contiguous in the packed layout
+        constexpr int PARTS = CK / CKC, TAP4 = CKC * COB / 4;
+        const f32x4* __restrict__ wc = reinterpret_cast<const f32x4*>(wcg + (long long)(chunk / PARTS) * Cfg::PACKED_CHUNK_FLOATS) + (chunk % PARTS) * TAP4;
 #pragma unroll
         for (int t = 0; t < NW4; ++t) {
             const int e4 = tid + 256 * t;
-            if (e4 < W_FLOATS / 4) wreg[t] = wc[e4];
+            if (e4 < W_FLOATS / 4) wreg[t] = wc[PARTS == 1 ? e4 : (e4 / TAP4) * (PARTS * TAP4) + e4 % TAP4];
         }
     };
     auto store_chunk = [&](int b, const float (&xin)[NIN], const f32x4 (&wreg)[NW4]) {
@@ -158,7 +164,7 @@ __global__ void __launch_bounds__(256, S == 1 ? 2 : 1) conv3x3_mfma_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
 
-    const int aoff = half * COB + l32;                                        // + (tap*CK + 2*kp)*COB + 32*mt
+    const int aoff = half * COB + l32;                                        // + (tap*CKC + 2*kp)*COB + 32*mt
     const int boff = half * (IH * IWP) + (2 * wv * S) * IWP + l32 * S;        // + (2*kp)*IH*IWP + (nt*S + dy)*IWP + dx
 
     // one chunk: 9 taps x 4 channel pairs x (2x2) MFMAs out of LDS buffer b
@@ -170,8 +176,8 @@ __global__ void __launch_bounds__(256, S == 1 ? 2 : 1) conv3x3_mfma_kernel(const
         const float* wb = inb + IN_FLOATS;
         auto operands = [&](int tap, int kp, float& a0, float& a1, float& b0, float& b1) {
             const int dy = tap / 3, dx = tap % 3;
-            a0 = wb[aoff + (tap * CK + 2 * kp) * COB];
-            a1 = wb[aoff + (tap * CK + 2 * kp) * COB + 32];
+            a0 = wb[aoff + (tap * CKC + 2 * kp) * COB];
+            a1 = wb[aoff + (tap * CKC + 2 * kp) * COB + 32];
             b0 = inb[boff + (2 * kp) * (IH * IWP) + dy * IWP + dx];
             b1 = inb[boff + (2 * kp) * (IH * IWP) + (S + dy) * IWP + dx];
         };
@@ -182,9 +188,9 @@ __global__ void __launch_bounds__(256, S == 1 ? 2 : 1) conv3x3_mfma_kernel(const
             if (tap == kFetchTap) fetch();
             if (tap == kRestageTap) restage();
 #pragma unroll
-            for (int kp = 0; kp < CK / 2; ++kp) {
+            for (int kp = 0; kp < CKC / 2; ++kp) {
                 float na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
-                if (kp + 1 < CK / 2) operands(tap, kp + 1, na0, na1, nb0, nb1);
+                if (kp + 1 < CKC / 2) operands(tap, kp + 1, na0, na1, nb0, nb1);
                 else if (tap + 1 < 9) operands(tap + 1, 0, na0, na1, nb0, nb1);
                 asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
@@ -196,7 +202,7 @@ __global__ void __launch_bounds__(256, S == 1 ? 2 : 1) conv3x3_mfma_kernel(const
         }
     };
 
-    const int nch = p.nchunks;
+    const int nch = (p.Cin + CKC - 1) / CKC;      // p.nchunks counts chunks of the packed layout (CK channels)
     load_chunk(0, xinA, wregA);
     store_chunk(0, xinA, wregA);
     __syncthreads();
@@ -470,6 +476,8 @@ extern "C" int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, 
     p.Wo = (d->W - 1) / d->stride + 1;
     if ((long long)d->Cin * d->H * d->W >= (1ll << 31)) return fail(KMSR_E_UNSUPPORTED, "per-image input exceeds 2^31 elements");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (d->Cout > kSmallCoMax && (long long)CK * d->H * d->W * 4 >= (1ll << 32))
+        return fail(KMSR_E_UNSUPPORTED, "conv3x3: %d x %d planes exceed the 32-bit buffer offsets of a channel chunk", d->H, d->W);
     if (d->Cout <= kSmallCoMax) {
         if (d->stride != 1) return fail(KMSR_E_UNSUPPORTED, "stride 2 with Cout <= %d is not implemented", kSmallCoMax);
         if (d->pixel_shuffle) return fail(KMSR_E_UNSUPPORTED, "pixel_shuffle with Cout <= %d is not implemented", kSmallCoMax);

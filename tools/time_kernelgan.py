@@ -11,7 +11,8 @@ with torch.no_grad():
         for w in band: w.mul_(30.0)
 N = 512
 x = torch.rand(N, 5, 256, 256, device="cuda")
-for bs in (8, 64, 512):
+BATCHES = tuple(int(a) for a in sys.argv[1:]) or (8, 64, 512)      # e.g. `time_kernelgan.py 512` under rocprofv3 for the bench shape alone
+for bs in BATCHES:
     for _ in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         outs = [g.extract_effective_kernels(x[s:s + bs], reduce_batch=False) for s in range(0, N, bs)]
