@@ -36,7 +36,9 @@ struct SmallCiParams {
 // UNSH (round 4): the output is stored PIXEL-UNSHUFFLED -- out[n, 4 co + 2 (y & 1) + (x & 1), y >> 1, x >> 1] -- and every lane keeps running
 // sums of what it stores per (row parity, channel): the data gradient of the SR tail then arrives in the layout the F -> 4F layer below
 // wants as its output gradient, with that layer's bias gradient, and no pass re-reads the HR-sized map (kmsr_conv3x3_smallci_unshuffle_fwd_f32).
-template <int CP2, bool UNSH>      // channel pairs: Cin padded to 2 * CP2
+// NCB (round 4): 32-channel output blocks per item.  Cout <= 32 (the KernelGAN condition encoder's 5 -> 32 layer: 4.3 GB of output per 512
+// patches) runs ONE block -- with two, half of the MFMAs multiplied zero weights and the layer was bound by that (2.2 ms where the write takes 1.1).
+template <int CP2, bool UNSH, int NCB = 2>      // channel pairs: Cin padded to 2 * CP2
 __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __restrict__ xg, const float* __restrict__ wg,
                                                                  const float* __restrict__ bias, float* __restrict__ out,
                                                                  float* __restrict__ usum, SmallCiParams p) {
@@ -100,11 +102,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
     };
 
     // ---- weights -> registers, once per (workgroup, cout group); re-read when the item's cout group changes
-    float areg[2][9 * CP2];
+    float areg[NCB][9 * CP2];
     int cg_loaded = -1;
     auto load_weights = [&](int cg) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
+        for (int cb = 0; cb < NCB; ++cb) {
             const int co = cg * 64 + cb * 32 + l32;
 #pragma unroll
             for (int t = 0; t < 9; ++t)
@@ -131,6 +133,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
     }
     store_stage(0);
     __syncthreads();
+    static_assert(!UNSH || NCB == 2, "the un-shuffled form keeps sums for both channel blocks");
     float cs[UNSH ? 2 : 1][2][16];                              // UNSH: running sums per (row parity, co block, register) of this lane's stores
 #pragma unroll
     for (int a = 0; a < (UNSH ? 2 : 1); ++a)
@@ -150,16 +153,16 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
         }
         const float* st = lds + b * TILE_F + lbase;
         const auto ro = __builtin_amdgcn_make_buffer_rsrc(out + ((long long)n * p.Cout + cg * 64) * HW, 0,
-                                                          (unsigned)min(64, p.Cout - cg * 64) * HWb, 0x00020000);
+                                                          (unsigned)min(32 * NCB, p.Cout - cg * 64) * HWb, 0x00020000);
         // wave wv owns output rows 2 wv, 2 wv + 1 of the tile = 4 groups of 32 pixels; two groups are multiplied together
         // (4 independent accumulator tiles keep the 64-cycle MFMA chain busy)
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {                        // gp = row of the pair
-            f32x16 acc[2][2];                                    // [column half][co block]
+            f32x16 acc[2][NCB];                                  // [column half][co block]
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {             // accumulators start at the bias: D rows co = (r & 3) + 8 (r >> 2) + 4 half
                         const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + cb * 32 + 8 * g4 + 4 * half);
@@ -173,10 +176,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
                 for (int q = 0; q < CP2; ++q) {
                     const int off = (2 * q) * QPLANE + (row + t / 3) * QPITCH + t % 3;
                     const float b0 = st[off], b1 = st[off + 32];
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[0][t * CP2 + q], b0, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[1][t * CP2 + q], b0, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[0][t * CP2 + q], b1, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[1][t * CP2 + q], b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[cb][t * CP2 + q], b0, acc[0][cb], 0, 0, 0);
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) acc[1][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[cb][t * CP2 + q], b1, acc[1][cb], 0, 0, 0);
                 }
             const int y = y0 + row;
 #pragma unroll
@@ -189,7 +192,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
                 else
                     vbase = inimg ? (unsigned)(y * W + x) * 4u : OOB;
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int col = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // channel within the group (past Cout: dropped by the range check)
@@ -273,11 +276,20 @@ extern "C" int kmsr_conv3x3_smallci_fwd_f32(const kmsr_conv3x3_desc* d, const fl
     }
     const int grid = (int)std::min<long long>(items, 2ll * cus);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    switch ((d->Cin + 1) / 2) {
-        case 1: conv3x3_smallci_kernel<1, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
-        case 2: conv3x3_smallci_kernel<2, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
-        case 3: conv3x3_smallci_kernel<3, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
-        default: conv3x3_smallci_kernel<4, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+    if (d->Cout <= 32) {        // one 32-channel block per item (cgs == 1)
+        switch ((d->Cin + 1) / 2) {
+            case 1: conv3x3_smallci_kernel<1, false, 1><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+            case 2: conv3x3_smallci_kernel<2, false, 1><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+            case 3: conv3x3_smallci_kernel<3, false, 1><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+            default: conv3x3_smallci_kernel<4, false, 1><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+        }
+    } else {
+        switch ((d->Cin + 1) / 2) {
+            case 1: conv3x3_smallci_kernel<1, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+            case 2: conv3x3_smallci_kernel<2, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+            case 3: conv3x3_smallci_kernel<3, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+            default: conv3x3_smallci_kernel<4, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+        }
     }
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;

@@ -257,6 +257,9 @@ SMALLCI_CASES = [  # N, Cin, H, W, Cout, bias, relu
     (1, 7, 16, 64, 70, True, False),        # Cout not a multiple of 64: channels past Cout dropped by the range check
     (3, 1, 8, 8, 32, True, True),           # one input channel, one 32-channel block, tile larger than the image
     (1, 5, 200, 256, 64, True, False),      # more items than persistent workgroups would get on a small grid
+    (2, 5, 40, 136, 32, True, True),        # round 4: the one-block instance (Cout <= 32) at the condition encoder's 5 -> 32
+    (1, 3, 21, 68, 32, True, False),        # one-block instance, odd height, two column tiles
+    (1, 8, 16, 64, 33, False, True),        # Cout = 33: just past one block -> the two-block instance
 ]
 
 
