@@ -299,8 +299,7 @@ __global__ void __launch_bounds__(256) conv3x3_smallco_kernel(const float* __res
                                                                const float* __restrict__ res, float* __restrict__ out,
                                                                ConvParams p) {
     constexpr int IN_FLOATS = SCK * SIH * SIWP;
-    constexpr int IN_ELEMS = SCK * SIH * SIW;
-    constexpr int NIN = (IN_ELEMS + 255) / 256;
+    constexpr int NIN = (IN_FLOATS + 255) / 256;
     __shared__ __attribute__((aligned(16))) float lds[2 * IN_FLOATS];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     int bid = blockIdx.x;
@@ -310,36 +309,33 @@ __global__ void __launch_bounds__(256) conv3x3_smallco_kernel(const float* __res
     const int H = p.H, W = p.W;
     const long long HW = (long long)H * W;
 
-    int goff[NIN];
+    // staging map over the LDS image itself: slot L = tid + 256 t of the [channel][row][SIWP] tile -> (c, r, col); its global BYTE offset from the
+    // chunk's first channel plane, or an offset no buffer covers for zero padding, the two pitch columns and the slots past the tile; channels
+    // past Cin fall off the end of the chunk's buffer.  A load is one buffer instruction and a stage write one ds_write_b32 at a compile-time
+    // offset from ONE base register -- neither costs a VALU instruction on a kernel that is VALU-bound (round 4).
+    unsigned goff[NIN];
 #pragma unroll
     for (int t = 0; t < NIN; ++t) {
         const int e = tid + 256 * t;
-        const int c = e / (SIH * SIW), rem = e - c * (SIH * SIW), r = rem / SIW, col = rem - r * SIW;
+        const int c = e / (SIH * SIWP), rem = e - c * (SIH * SIWP), r = rem / SIWP, col = rem - r * SIWP;
         const int gy = ty0 - 1 + r, gx = tx0 - 1 + col;
-        const bool ok = e < IN_ELEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        goff[t] = ok ? (int)(c * HW + (long long)gy * W + gx) : -1;
+        const bool ok = e < IN_FLOATS && col < SIW && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[t] = ok ? (unsigned)(c * HW + (long long)gy * W + gx) * 4u : 0xFFFFFFFFu;
     }
     const float* __restrict__ xn = xg + (long long)n * p.Cin * HW;
     float xin[NIN];
     auto load_chunk = [&](int chunk) {
-        const float* __restrict__ xc = xn + (long long)chunk * SCK * HW;
-        const int cin_left = p.Cin - chunk * SCK;
+        const long long left = ((long long)p.Cin - (long long)chunk * SCK) * HW * 4;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(xn + (long long)chunk * SCK * HW), 0, (unsigned)(left < 0xFFFFFFFFll ? left : 0xFFFFFFFFll), 0x00020000);
 #pragma unroll
-        for (int t = 0; t < NIN; ++t) {
-            const int c = (tid + 256 * t) / (SIH * SIW);
-            const bool ok = goff[t] >= 0 && c < cin_left;
-            const float v = xc[ok ? goff[t] : 0];
-            xin[t] = ok ? v : 0.f;
-        }
+        for (int t = 0; t < NIN; ++t) xin[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, goff[t], 0, 0));
     };
     auto store_chunk = [&](int b) {
-        float* inb = lds + b * IN_FLOATS;
+        float* inb = lds + b * IN_FLOATS + tid;
 #pragma unroll
-        for (int t = 0; t < NIN; ++t) {
-            const int e = tid + 256 * t;
-            const int c = e / (SIH * SIW), rem = e - c * (SIH * SIW), r = rem / SIW, col = rem - r * SIW;
-            if (e < IN_ELEMS) inb[(c * SIH + r) * SIWP + col] = xin[t];
-        }
+        for (int t = 0; t < NIN; ++t)
+            if (256 * t + 255 < IN_FLOATS || tid + 256 * t < IN_FLOATS) inb[256 * t] = xin[t];
     };
 
     // Accumulators as packed pairs of adjacent pixels: v_pk_fma_f32 issues two FMAs per slot with the (wave-uniform) weight
@@ -476,7 +472,7 @@ extern "C" int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, 
     p.Wo = (d->W - 1) / d->stride + 1;
     if ((long long)d->Cin * d->H * d->W >= (1ll << 31)) return fail(KMSR_E_UNSUPPORTED, "per-image input exceeds 2^31 elements");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (d->Cout > kSmallCoMax && (long long)CK * d->H * d->W * 4 >= (1ll << 32))
+    if ((long long)CK * d->H * d->W * 4 >= (1ll << 32))
         return fail(KMSR_E_UNSUPPORTED, "conv3x3: %d x %d planes exceed the 32-bit buffer offsets of a channel chunk", d->H, d->W);
     if (d->Cout <= kSmallCoMax) {
         if (d->stride != 1) return fail(KMSR_E_UNSUPPORTED, "stride 2 with Cout <= %d is not implemented", kSmallCoMax);
