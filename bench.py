@@ -793,7 +793,12 @@ def main():
     secondary = None
     if args.workload == "degrade_sr" and not args.no_secondary:
         hold = wl.roofline_degrade_northstar() if rank == 0 else None        # before the big secondary workloads exist
-        secondary = secondary_lines(device, rank, world, kd, sync)
+        try:
+            secondary = secondary_lines(device, rank, world, kd, sync)
+        except Exception as e:          # the headline above is already measured: report it, and say loudly what broke behind it
+            import traceback
+            secondary = {"failed": True, "error": f"{type(e).__name__}: {e}", "where": traceback.format_exc().strip().splitlines()[-3:]}
+            print(f"[bench] rank {rank}: secondary legs failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
     else:
         hold = None
 
