@@ -18,6 +18,7 @@
 #include "kmsr_common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace kmsr {
 namespace {
@@ -26,6 +27,10 @@ constexpr int CK = 8;     // input channels per chunk of the PACKED weight layou
 constexpr int TH = 8;     // output tile rows per block
 constexpr int TW = 32;    // output tile cols per block (= MFMA N)
 constexpr int COB = 64;   // output channels per block (2 MFMA M blocks)
+#ifndef KMSR_S2_FETCH
+#define KMSR_S2_FETCH 1
+#define KMSR_S2_RESTAGE 7
+#endif
 constexpr int kFetchTap = 1;    // the next chunk's global loads are issued before this tap (after the first tap's 16 MFMAs)
 constexpr int kRestageTap = 7;  // ... and written to the other LDS buffer before this tap (of 9)
 
@@ -47,8 +52,13 @@ template <int S>
 struct ConvCfg {
     static constexpr int IH = (TH - 1) * S + 3;
     static constexpr int IW = (TW - 1) * S + 3;
-    static constexpr int IWP = (IW + 3) / 4 * 4;
+    // stride 2: row pitch 72 with image column 2 tx0 - 4 at LDS column 0 (the tile's first column, 2 tx0 - 1, at COL0 = 3), so that rows can
+    // be staged as 18 aligned 16-byte pieces when W % 4 == 0 (WIDE instance); stride 1: pitch 36, first column at 0
+    static constexpr int IWP = S == 2 ? 72 : (IW + 3) / 4 * 4;
+    static constexpr int COL0 = S == 2 ? 3 : 0;
     static constexpr int CKC = S == 2 ? 4 : CK;                // input channels per LDS chunk; CK / CKC kernel chunks per packed chunk
+    static constexpr int QROW = IWP / 4;                       // 16-byte pieces per staged row (WIDE)
+    static constexpr int NQ4 = (CKC * IH * QROW + 255) / 256;  // pieces per thread and chunk (WIDE): 5
     static constexpr int IN_FLOATS = CKC * IH * IWP;
     static constexpr int W_FLOATS = 9 * CKC * COB;
     static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
@@ -79,14 +89,20 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Cin, int Co
     }
 }
 
-template <int S, bool PS>
+template <int S, bool PS, bool WIDE = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __restrict__ xg, const float* __restrict__ wpk,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ res, float* __restrict__ out,
                                                               ConvParams p) {
     using Cfg = ConvCfg<S>;
     constexpr int IH = Cfg::IH, IW = Cfg::IW, IWP = Cfg::IWP, IN_FLOATS = Cfg::IN_FLOATS, W_FLOATS = Cfg::W_FLOATS;
-    constexpr int BUF = Cfg::BUF_FLOATS, IN_ELEMS = Cfg::IN_ELEMS, NIN = Cfg::NIN, NW4 = Cfg::NW4, CKC = Cfg::CKC;
+    constexpr int BUF = Cfg::BUF_FLOATS, IN_ELEMS = Cfg::IN_ELEMS, NW4 = Cfg::NW4, CKC = Cfg::CKC, COL0 = Cfg::COL0;
+    static_assert(!WIDE || S == 2, "16-byte staging is built for the stride-2 tile");
+    // WIDE (stride 2, W % 4 == 0, 16-byte aligned x): a staged element is an aligned 16-byte piece of a row -- 5 loads and 5 ds_write_b128 per
+    // thread and chunk instead of 18 + 18 dword ones.  Every vector-memory instruction issued inside the MFMA stream holds the wave's issue
+    // for 20-50 cycles (tools/ubench/mfma_store.hip): the 18 loads were most of what the "no loads" ablation gave back (18 % of the kernel).
+    using stage_t = std::conditional_t<WIDE, f32x4, float>;
+    constexpr int NIN = WIDE ? Cfg::NQ4 : Cfg::NIN, QROW = Cfg::QROW;
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
     const int tid = threadIdx.x;
@@ -108,13 +124,26 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __res
     // ---- staging map of the input halo tile (same for every chunk): BYTE offsets from the chunk's first channel plane; zero padding and
     //      the slots past the tile get an offset no buffer covers (the host checks CK * H * W * 4 < 2^32)
     unsigned goff[NIN];
+    int loff[NIN];                              // the slot's LDS position inside a buffer (floats)
 #pragma unroll
     for (int t = 0; t < NIN; ++t) {
         const int e = tid + 256 * t;
-        const int c = e / (IH * IW), rem = e - c * (IH * IW), r = rem / IW, col = rem - r * IW;
-        const int gy = ty0 * S - 1 + r, gx = tx0 * S - 1 + col;
-        const bool ok = e < IN_ELEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        goff[t] = ok ? (unsigned)(c * HW + (long long)gy * W + gx) * 4u : 0xFFFFFFFFu;
+        if constexpr (WIDE) {
+            const int c = e / (IH * QROW), rem = e - c * (IH * QROW), r = rem / QROW, k = rem - r * QROW;
+            const int gy = ty0 * S - 1 + r, gx = tx0 * S - 4 + 4 * k;           // W % 4 == 0: a piece is entirely inside or outside the row
+            const bool ok = e < CKC * IH * QROW && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            goff[t] = ok ? (unsigned)(c * HW + (long long)gy * W + gx) * 4u : 0xFFFFFFFFu;
+            loff[t] = e < CKC * IH * QROW ? (c * IH + r) * IWP + 4 * k : -1;
+        } else {
+            const int c = e / (IH * IW), rem = e - c * (IH * IW), r = rem / IW, col = rem - r * IW;
+            const int gy = ty0 * S - 1 + r, gx = tx0 * S - 1 + col;
+            const bool ok = e < IN_ELEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            goff[t] = ok ? (unsigned)(c * HW + (long long)gy * W + gx) * 4u : 0xFFFFFFFFu;
+            loff[t] = e < IN_ELEMS ? (c * IH + r) * IWP + COL0 + col : -1;
+        }
+#ifdef KMSR_ABL_NOLOAD      // timing ablation (tools/diag/ab_s2.sh): every input load out of range -> zeros, no memory traffic
+        goff[t] = 0xFFFFFFFFu;
+#endif
     }
     const float* __restrict__ xn = xg + (long long)n * p.Cin * HW;
     const float* __restrict__ wcg = wpk + (long long)cg * p.nchunks * Cfg::PACKED_CHUNK_FLOATS;
@@ -122,15 +151,18 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __res
     // One register staging set: the next chunk's global loads are ISSUED after the first tap's MFMAs (their ~80
     // address/load instructions then issue in the shadow of the matrix pipe instead of ahead of it) and are written
     // to the other LDS buffer before tap kRestageTap of the same phase.
-    float xinA[NIN];
+    stage_t xinA[NIN];
     f32x4 wregA[NW4];
-    auto load_chunk = [&](int chunk, float (&xin)[NIN], f32x4 (&wreg)[NW4]) {
+    auto load_chunk = [&](int chunk, stage_t (&xin)[NIN], f32x4 (&wreg)[NW4]) {
         // the buffer = what is left of this image from the chunk's first channel: channels past Cin are out of range too (channel padding)
         const long long left = ((long long)p.Cin - (long long)chunk * CKC) * HW * 4;
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(xn + (long long)chunk * CKC * HW), 0, (unsigned)(left < 0xFFFFFFFFll ? left : 0xFFFFFFFFll), 0x00020000);
 #pragma unroll
-        for (int t = 0; t < NIN; ++t) xin[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, goff[t], 0, 0));
+        for (int t = 0; t < NIN; ++t) {
+            if constexpr (WIDE) xin[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, goff[t], 0, 0));
+            else xin[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, goff[t], 0, 0));
+        }
         // kernel chunk -> (packed chunk, part): per tap the part's CKC x COB floats are contiguous in the packed layout
         constexpr int PARTS = CK / CKC, TAP4 = CKC * COB / 4;
         const f32x4* __restrict__ wc = reinterpret_cast<const f32x4*>(wcg + (long long)(chunk / PARTS) * Cfg::PACKED_CHUNK_FLOATS) + (chunk % PARTS) * TAP4;
@@ -140,15 +172,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __res
             if (e4 < W_FLOATS / 4) wreg[t] = wc[PARTS == 1 ? e4 : (e4 / TAP4) * (PARTS * TAP4) + e4 % TAP4];
         }
     };
-    auto store_chunk = [&](int b, const float (&xin)[NIN], const f32x4 (&wreg)[NW4]) {
+    auto store_chunk = [&](int b, const stage_t (&xin)[NIN], const f32x4 (&wreg)[NW4]) {
         float* inb = lds + b * BUF;
         float* wb = inb + IN_FLOATS;
 #pragma unroll
-        for (int t = 0; t < NIN; ++t) {
-            const int e = tid + 256 * t;
-            const int c = e / (IH * IW), rem = e - c * (IH * IW), r = rem / IW, col = rem - r * IW;
-            if (e < IN_ELEMS) inb[(c * IH + r) * IWP + col] = xin[t];
-        }
+        for (int t = 0; t < NIN; ++t)
+            if (loff[t] >= 0) *reinterpret_cast<stage_t*>(inb + loff[t]) = xin[t];
 #pragma unroll
         for (int t = 0; t < NW4; ++t) {
             const int e4 = tid + 256 * t;
@@ -165,7 +194,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __res
             for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
 
     const int aoff = half * COB + l32;                                        // + (tap*CKC + 2*kp)*COB + 32*mt
-    const int boff = half * (IH * IWP) + (2 * wv * S) * IWP + l32 * S;        // + (2*kp)*IH*IWP + (nt*S + dy)*IWP + dx
+    const int boff = half * (IH * IWP) + (2 * wv * S) * IWP + l32 * S + COL0;  // + (2*kp)*IH*IWP + (nt*S + dy)*IWP + dx
 
     // one chunk: 9 taps x 4 channel pairs x (2x2) MFMAs out of LDS buffer b
     // The 4 operands of group (tap, kp) are requested one group AHEAD of their MFMAs (register pins keep hipcc from sinking the
@@ -185,8 +214,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __res
         operands(0, 0, a0, a1, b0, b1);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap == kFetchTap) fetch();
-            if (tap == kRestageTap) restage();
+            if (tap == (S == 2 ? KMSR_S2_FETCH : kFetchTap)) fetch();
+            if (tap == (S == 2 ? KMSR_S2_RESTAGE : kRestageTap)) restage();
 #pragma unroll
             for (int kp = 0; kp < CKC / 2; ++kp) {
                 float na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
@@ -203,15 +232,40 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __res
     };
 
     const int nch = (p.Cin + CKC - 1) / CKC;      // p.nchunks counts chunks of the packed layout (CK channels)
-    load_chunk(0, xinA, wregA);
-    store_chunk(0, xinA, wregA);
-    __syncthreads();
-    for (int chunk = 0; chunk < nch; ++chunk) {
-        const int b = chunk & 1;
-        const bool more = chunk + 1 < nch;   // block-uniform
-        mma_chunk(b, [&] { if (more) load_chunk(chunk + 1, xinA, wregA); },
-                  [&] { if (more) store_chunk(b ^ 1, xinA, wregA); });   // the other buffer was last read before the previous barrier
+    if constexpr (S == 2) {
+        // Two register staging sets: chunk k + 2 is REQUESTED during chunk k and written to LDS during chunk k + 1.  One chunk of lookahead is
+        // 48 MFMAs of this wave between request and use; a chunk's 204 L2-missing lines drain through the CU's 64-entry miss queue in
+        // ~3 500 cycles while the partner workgroup's requests queue behind them: the "no loads" ablation said the
+        // waits cost 18 % of the kernel (tools/diag/ab_s2.sh, round 4).
+        stage_t xinB[NIN];
+        f32x4 wregB[NW4];
+        load_chunk(0, xinA, wregA);
+        if (nch > 1) load_chunk(1, xinB, wregB);
+        store_chunk(0, xinA, wregA);
         __syncthreads();
+        for (int chunk = 0; chunk < nch; chunk += 2) {
+            {   // even chunk: LDS buffer 0; request chunk + 2 into set A (free since chunk's own restage), write chunk + 1 from set B
+                const bool m2 = chunk + 2 < nch, m1 = chunk + 1 < nch;      // block-uniform
+                mma_chunk(0, [&] { if (m2) load_chunk(chunk + 2, xinA, wregA); }, [&] { if (m1) store_chunk(1, xinB, wregB); });
+                __syncthreads();
+            }
+            if (chunk + 1 < nch) {
+                const bool m2 = chunk + 3 < nch, m1 = chunk + 2 < nch;
+                mma_chunk(1, [&] { if (m2) load_chunk(chunk + 3, xinB, wregB); }, [&] { if (m1) store_chunk(0, xinA, wregA); });
+                __syncthreads();
+            }
+        }
+    } else {
+        load_chunk(0, xinA, wregA);
+        store_chunk(0, xinA, wregA);
+        __syncthreads();
+        for (int chunk = 0; chunk < nch; ++chunk) {
+            const int b = chunk & 1;
+            const bool more = chunk + 1 < nch;   // block-uniform
+            mma_chunk(b, [&] { if (more) load_chunk(chunk + 1, xinA, wregA); },
+                      [&] { if (more) store_chunk(b ^ 1, xinA, wregA); });   // the other buffer was last read before the previous barrier
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: bias, ReLU, residual, (PixelShuffle) store.  No per-element branches around loads: the bias goes
@@ -276,7 +330,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const float* __res
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
+#ifdef KMSR_ABL_NOSTORE     // timing ablation: the stores are compiled but never executed
+                    if (ok[r] && p.N < 0) out[idx[r]] = v[r];
+#else
                     if (ok[r]) out[idx[r]] = v[r];
+#endif
             }
         }
     }
@@ -500,6 +558,8 @@ extern "C" int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, 
     p.n_blocks = (int)nblocks;
     if (d->pixel_shuffle)
         conv3x3_mfma_kernel<1, true><<<p.n_blocks, 256, 0, stream>>>(x, packed_w, bias, residual, out, p);
+    else if (d->stride == 2 && d->W % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0)
+        conv3x3_mfma_kernel<2, false, true><<<p.n_blocks, 256, 0, stream>>>(x, packed_w, bias, residual, out, p);
     else if (d->stride == 2)
         conv3x3_mfma_kernel<2, false><<<p.n_blocks, 256, 0, stream>>>(x, packed_w, bias, residual, out, p);
     else

@@ -152,6 +152,23 @@ def test_wino4_argument_checks_without_gpu():
     assert lib.kmsr_conv3x3_wino4_fwd_f32(d, p(0x1004), p(0x1000), None, None, p(0x1000), None) == L.KMSR_E_BADARG
 
 
+def test_direct_conv_argument_checks_without_gpu():
+    """kmsr_conv3x3_fwd_f32 (round 4: input tiles staged by buffer loads with 32-bit byte offsets inside an 8-channel chunk) rejects planes whose
+    chunk does not fit those offsets, and the shapes it never served, before any launch."""
+    lib = L.load()
+    d = L.Conv3x3Desc()
+    p = lambda a: C.c_void_p(a)
+    d.N, d.Cin, d.H, d.W, d.Cout, d.stride = 1, 8, 16384, 8192, 64, 1                   # 2^27 pixels per plane: 8 planes = 2^32 bytes
+    assert lib.kmsr_conv3x3_fwd_f32(d, p(0x1000), p(0x1000), None, None, p(0x1000), None) == L.KMSR_E_UNSUPPORTED
+    assert b"32-bit buffer offsets" in lib.kmsr_last_error()
+    d.Cout = 3                                                                           # the small-Cout kernel stages the same way
+    assert lib.kmsr_conv3x3_fwd_f32(d, p(0x1000), p(0x1000), None, None, p(0x1000), None) == L.KMSR_E_UNSUPPORTED
+    d.H, d.W, d.Cout, d.stride = 16, 16, 64, 3
+    assert lib.kmsr_conv3x3_fwd_f32(d, p(0x1000), p(0x1000), None, None, p(0x1000), None) == L.KMSR_E_UNSUPPORTED
+    d.stride = 1
+    assert lib.kmsr_conv3x3_fwd_f32(d, None, p(0x1000), None, None, p(0x1000), None) == L.KMSR_E_BADARG
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():

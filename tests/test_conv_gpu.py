@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 import kmsr_amd
 from kmsr_amd import _lib as L
-from kmsr_amd.sr import SRNet, conv3x3, pack_conv3x3_weight, psnr
+from kmsr_amd.sr import SRNet, conv3x3, pack_conv3x3_weight, pack_for, psnr
 from oracle.sr_torch import SRNetTorch
 
 pytestmark = pytest.mark.gpu
@@ -49,6 +49,38 @@ CASES = [
     (3, 20, 9, 31, 12, True, False, True, False),       # Cin spans 3 chunks with a partial one, tiny image
     (1, 16, 1, 1, 16, True, True, False, True),         # 1x1 image, PixelShuffle
 ]
+
+
+S2_CASES = [
+    # N, Cin, H, W, Cout, bias, relu
+    (2, 32, 64, 136, 64, True, True),       # 16-byte staging (W % 4 == 0): 3 column tiles, ragged right edge, the encoder's 32 -> 64
+    (1, 64, 33, 68, 64, True, False),       # odd height: the last output row reads the bottom padding
+    (1, 32, 40, 70, 64, False, True),       # W % 4 != 0: the dword-staged instance
+    (2, 5, 17, 31, 32, True, True),         # odd everything, Cin inside one half chunk, Cout below the block
+    (1, 22, 16, 64, 100, True, False),      # Cin = 5 half chunks + a partial one, two cout groups with a ragged one
+    (1, 64, 2, 4, 64, True, True),          # image smaller than the tile
+    (1, 4, 1, 1, 16, False, False),         # 1 x 1 image: one tap inside
+]
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,bias,relu", S2_CASES)
+def test_conv3x3_stride2_vs_torch(N, Cin, H, W, Cout, bias, relu, gpu_device):
+    """kmsr_conv3x3_fwd_f32 with stride 2 (SelectorNet / ConditionEncoder, moe_network.py:17-19, muti_kernel/networks.py:22-26): half-chunk staging,
+    buffer-load padding, the 16-byte staged instance (round 4) and its dword fallback against a float64 convolution."""
+    g = torch.Generator().manual_seed(7 * N + Cin + 3 * Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g) if bias else None
+    out = conv3x3(x.cuda(), pack_for("direct", w.cuda()), Cout, bias=None if b is None else b.cuda(), relu=relu, stride=2)
+    assert out.shape == (N, Cout, (H + 1) // 2, (W + 1) // 2)
+    _check(out, _ref_conv(x, w, b, relu, None, False, stride=2), tol=1e-5, what=f"stride-2 {Cin}->{Cout} {H}x{W}")
+    # a view that is not 16-byte aligned takes the dword instance and must give the same numbers
+    if W % 4 == 0:
+        xp = torch.zeros(N * Cin * H * W + 1, device=gpu_device)
+        xv = xp[1:].view(N, Cin, H, W)
+        xv.copy_(x)
+        out2 = conv3x3(xv, pack_for("direct", w.cuda()), Cout, bias=None if b is None else b.cuda(), relu=relu, stride=2)
+        assert torch.equal(out, out2)
 
 
 @pytest.mark.parametrize("N,Cin,H,W,Cout,bias,relu,res,ps", CASES)
