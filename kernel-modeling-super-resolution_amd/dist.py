@@ -131,7 +131,12 @@ class GradBucket:
     unless the step uses gradient-accumulation micro-steps or back-propagates several losses separately); a slice is launched
     when its parameters have received their n-th gradient.  A hook that fires for a slice already in flight (more backward
     passes than declared) raises instead of silently adding local gradients to a reduced slice.  `always_reduce=True` runs
-    the collective at world size 1 as well (the RCCL smoke test: the sum over one rank is the identity)."""
+    the collective at world size 1 as well (the RCCL smoke test: the sum over one rank is the identity).
+
+    Round 4 -- no accumulate kernels: zero() sets the gradients to None, so autograd's first (usually only) gradient of a parameter is taken
+    over as produced instead of being added into a zeroed view (76 adds + the memset per SR training step); a slice is GATHERED into the
+    flat buffer -- one multi-tensor copy -- when it completes (from the hook when the overlap is armed, else in all_reduce_mean() / finish()),
+    and from then on `p.grad` is the view of the flat buffer again: what the optimizer, the collective and `flat` readers see is unchanged."""
 
     def __init__(self, params, chunks=2, always_reduce=False):
         self.always_reduce = bool(always_reduce)
@@ -139,9 +144,10 @@ class GradBucket:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off, offs = 0, []
+        off, offs, self._views = 0, [], []
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self._views.append(self.flat[off:off + p.numel()].view_as(p))
+            p.grad = self._views[-1]
             offs.append(off)
             off += p.numel()
         # slice boundaries: parameter boundaries closest to k*n/chunks
@@ -163,12 +169,33 @@ class GradBucket:
                 self._slice_of[id(p)] = k
         self._armed = False
         self._pending, self._works = [], []
+        self._gathered = [True] * len(self._slices)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _distributed(self):
         return dist.is_initialized() and (dist.get_world_size() > 1 or self.always_reduce)
 
+    def _gather(self, k):
+        """Slice k's gradients -> the flat buffer (one multi-tensor copy); the parameters' .grad become the buffer's views again."""
+        if self._gathered[k]:
+            return
+        a, b, _, _ = self._slices[k]
+        dst, src = [], []
+        for p, v in zip(self.params[a:b], self._views[a:b]):
+            g = p.grad
+            if g is None:
+                v.zero_()                               # no gradient reached this parameter in this step
+            elif g.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(g.detach())
+            p.grad = v
+        if dst:
+            with torch.no_grad():
+                torch._foreach_copy_(dst, src)
+        self._gathered[k] = True
+
     def _launch(self, k):
+        self._gather(k)
         _, _, a, b = self._slices[k]
         self._works[k] = dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True)
 
@@ -185,9 +212,11 @@ class GradBucket:
             self._launch(k)
 
     def zero(self, backwards=1, overlap=True):
-        """Clear the gradients and arm the overlap hooks for the `backwards` backward passes that follow (overlap=False: no
+        """Drop the gradients (None: the next backward's gradients are taken over, not added to zeros) and arm the overlap hooks for the `backwards` backward passes that follow (overlap=False: no
         hook launches anything, finish() / all_reduce_mean() reduce the whole bucket)."""
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
+        self._gathered = [False] * len(self._slices)
         self._pending = [(b - a) * max(int(backwards), 1) for a, b, _, _ in self._slices]
         self._works = [None] * len(self._slices)
         self._armed = bool(overlap) and self._distributed()
@@ -199,9 +228,11 @@ class GradBucket:
     def all_reduce_mean(self, async_op=False):
         """Average gradients over ranks.  async_op=True returns the work handles (call .finish(handles) before the optimizer
         step); slices the hooks already launched during backward are not launched again."""
+        self._armed = False
+        for k in range(len(self._slices)):
+            self._gather(k)
         if not self._distributed():
             return None
-        self._armed = False
         if len(self._works) != len(self._slices):
             self._works = [None] * len(self._slices)
         for k in range(len(self._slices)):
@@ -214,10 +245,10 @@ class GradBucket:
         return None
 
     def finish(self, work=None):
-        if not self._distributed():
-            return
         if work is None:
             work = self.all_reduce_mean(async_op=True)
+        if not self._distributed() or work is None:
+            return
         for w in work:
             w.wait()
         self.flat.div_(dist.get_world_size())
