@@ -206,7 +206,10 @@ int kmsr_conv3x3_smallci_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, con
  * conv(x, w)[n, co, y, x] (+ bias, ReLU), and chan_sums[4 Cout] receives sum_{n,y,x} of every output channel (fixed order).  It is the data
  * gradient of the SR tail (bands -> F at HR size) delivered in the layout the F -> 4F + PixelShuffle(2) layer below takes as its output
  * gradient, together with that layer's bias gradient: replaces kmsr_pixel_unshuffle2_sum_f32's extra pass over the HR-sized map.
- * Cin <= 8, Cout <= 64, even H, W % 4 == 0.  workspace: kmsr_conv3x3_smallci_unshuffle_workspace_bytes(d). */
+ * Cin <= 8, Cout <= 64, even H, W % 4 == 0.  workspace: kmsr_conv3x3_smallci_unshuffle_workspace_bytes(d).
+ * chan_sums may be NULL (then workspace may be NULL too): store only -- the 64 per-lane sum registers push the kernel over its two-workgroups-
+ * per-CU register budget (4.7 vs 2.5 ms at config 3), and a caller that knows the input's parity / border sums has the channel sums in closed
+ * form (sum_p conv(x, w)[co, p] = sum_{ci,tap} w[co,ci,tap] * (sum of x[ci] over the pixels tap reaches): kmsr_amd/sr.py, UpTailFunction). */
 size_t kmsr_conv3x3_smallci_unshuffle_workspace_bytes(const kmsr_conv3x3_desc* d);
 int kmsr_conv3x3_smallci_unshuffle_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* w, const float* bias, float* out,
                                            float* chan_sums, void* workspace, size_t workspace_bytes, void* stream);

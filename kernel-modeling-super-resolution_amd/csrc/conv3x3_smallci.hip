@@ -34,11 +34,18 @@ struct SmallCiParams {
 };
 
 // UNSH (round 4): the output is stored PIXEL-UNSHUFFLED -- out[n, 4 co + 2 (y & 1) + (x & 1), y >> 1, x >> 1] -- and every lane keeps running
-// sums of what it stores per (row parity, channel): the data gradient of the SR tail then arrives in the layout the F -> 4F layer below
+// sums of what it stores per (column parity, channel): the data gradient of the SR tail then arrives in the layout the F -> 4F layer below
 // wants as its output gradient, with that layer's bias gradient, and no pass re-reads the HR-sized map (kmsr_conv3x3_smallci_unshuffle_fwd_f32).
+// The MFMA's N index is free to name any 32 pixels: here lane l32 of column half ch multiplies pixel x = 2 l32 + ch (the B operand is a
+// stride-2 ds_read_b32: 32 distinct banks), so one accumulator register holds the 32 pixels of ONE sub-pixel plane at consecutive
+// positions and an un-shuffled store is a full 128-byte line, like the plain store (the first form kept lane = x and wrote every line as two
+// 64-byte halves from different instructions: 2.5 ms slower per training step than a separate un-shuffle pass).  Wave wv owns rows wv and
+// wv + 4 of the tile, so the row parity is the wave's and the sums need the same 64 registers as before.
 // NCB (round 4): 32-channel output blocks per item.  Cout <= 32 (the KernelGAN condition encoder's 5 -> 32 layer: 4.3 GB of output per 512
 // patches) runs ONE block -- with two, half of the MFMAs multiplied zero weights and the layer was bound by that (2.2 ms where the write takes 1.1).
-template <int CP2, bool UNSH, int NCB = 2>      // channel pairs: Cin padded to 2 * CP2
+// SUMS: the un-shuffled form also keeps the per-lane channel sums (64 more live registers: with them the 2-workgroups-per-CU register budget
+// spills 188 VGPRs and the layer takes 4.7 instead of 2.5 ms at config 3 -- the caller that can get the sums elsewhere passes chan_sums = NULL).
+template <int CP2, bool UNSH, int NCB = 2, bool SUMS = UNSH>      // channel pairs: Cin padded to 2 * CP2
 __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __restrict__ xg, const float* __restrict__ wg,
                                                                  const float* __restrict__ bias, float* __restrict__ out,
                                                                  float* __restrict__ usum, SmallCiParams p) {
@@ -133,15 +140,16 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
     }
     store_stage(0);
     __syncthreads();
-    static_assert(!UNSH || NCB == 2, "the un-shuffled form keeps sums for both channel blocks");
-    float cs[UNSH ? 2 : 1][2][16];                              // UNSH: running sums per (row parity, co block, register) of this lane's stores
+    static_assert(!UNSH || NCB == 2, "the un-shuffled form stores both channel blocks");
+    static_assert(!SUMS || UNSH, "channel sums belong to the un-shuffled form");
+    float cs[SUMS ? 2 : 1][2][16];                              // UNSH: running sums per (row parity, co block, register) of this lane's stores
 #pragma unroll
-    for (int a = 0; a < (UNSH ? 2 : 1); ++a)
+    for (int a = 0; a < (SUMS ? 2 : 1); ++a)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) cs[a][cb][r] = 0.f;
-    const int lbase = half * QPLANE + 3 + l32;                 // B operand: k = half picks the plane of the pair, pixel l32; + taps / group offsets
+    const int lbase = half * QPLANE + 3 + (UNSH ? 2 * l32 : l32);   // B operand: k = half picks the plane of the pair, pixel l32 (UNSH: 2 l32 + ch); + taps / group offsets
     for (; it < p.n_items; it += gridDim.x) {
         const int nxt = it + gridDim.x;
         const bool more = nxt < p.n_items;
@@ -169,13 +177,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
                         acc[ch][cb][4 * g4 + 0] = b4.x; acc[ch][cb][4 * g4 + 1] = b4.y;
                         acc[ch][cb][4 * g4 + 2] = b4.z; acc[ch][cb][4 * g4 + 3] = b4.w;
                     }
-            const int row = 2 * wv + gp;                         // output row inside the tile; input rows row .. row + 2
+            const int row = UNSH ? wv + 4 * gp : 2 * wv + gp;    // output row inside the tile; input rows row .. row + 2
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
                 for (int q = 0; q < CP2; ++q) {
                     const int off = (2 * q) * QPLANE + (row + t / 3) * QPITCH + t % 3;
-                    const float b0 = st[off], b1 = st[off + 32];
+                    const float b0 = st[off], b1 = st[off + (UNSH ? 1 : 32)];
 #pragma unroll
                     for (int cb = 0; cb < NCB; ++cb) acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[cb][t * CP2 + q], b0, acc[0][cb], 0, 0, 0);
 #pragma unroll
@@ -184,7 +192,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
             const int y = y0 + row;
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
-                const int x = x0 + 32 * ch + l32;
+                const int x = UNSH ? x0 + 2 * l32 + ch : x0 + 32 * ch + l32;
                 const bool inimg = y < H && x < W;
                 unsigned vbase;
                 if constexpr (UNSH)     // the 4 sub-pixel planes of a channel occupy the channel's HW floats: same channel stride
@@ -199,7 +207,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
                         float v = acc[ch][cb][r];
                         if (p.relu) v = fmaxf(v, 0.f);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, vbase + (unsigned)col * HWb, 0, 0);
-                        if constexpr (UNSH) cs[gp][cb][r] += inimg ? v : 0.f;
+                        if constexpr (SUMS) cs[ch][cb][r] += inimg ? v : 0.f;
                     }
             }
         }
@@ -215,7 +223,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
         __syncthreads();
         b ^= 1;
     }
-    if constexpr (UNSH) {       // per-lane partial sums [block][wave][lane][row parity][co block][register]; reduced in a fixed order by the kernel below
+    if constexpr (SUMS) {       // per-lane partial sums [block][wave][lane][column parity][co block][register] (row parity = wave & 1); reduced in a fixed order below
         float* o = usum + ((long long)(blockIdx.x * 4 + wv) * 64 + lane) * 64;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -227,15 +235,16 @@ __global__ void __launch_bounds__(256, 2) conv3x3_smallci_kernel(const float* __
     }
 }
 
-// sums[4 co + 2 yp + xp] = sum over blocks, waves and the 16 lanes of (k half, column parity xp) of their partials (fixed order: bit-reproducible)
+// sums[4 co + 2 yp + xp] = sum over blocks, the two waves of row parity yp and the 32 lanes of the channel's k half of their partials (fixed
+// order: bit-reproducible)
 __global__ void __launch_bounds__(256) smallci_unshuffle_sum_kernel(const float* __restrict__ usum, int nblocks, float* __restrict__ sums) {
     const int k = blockIdx.x, co = k >> 2, yp = (k >> 1) & 1, xp = k & 1;
     const int cb = co >> 5, c5 = co & 31, half = (c5 >> 2) & 1, r = (c5 & 3) + 4 * (c5 >> 3);
-    const int total = nblocks * 4 * 16;                       // (block, wave, lane of the class)
+    const int total = nblocks * 2 * 32;                       // (block, wave of the parity, lane of the half)
     float a = 0.f;
     for (int e = threadIdx.x; e < total; e += 256) {
-        const int j = e & 15, bw = e >> 4, lane = half * 32 + 2 * j + xp;
-        a += usum[((long long)bw * 64 + lane) * 64 + yp * 32 + cb * 16 + r];
+        const int j = e & 31, w2 = (e >> 5) & 1, blk = e >> 6, wave = 2 * w2 + yp, lane = half * 32 + j;
+        a += usum[((long long)(blk * 4 + wave) * 64 + lane) * 64 + xp * 32 + cb * 16 + r];
     }
     __shared__ float red[256];
     red[threadIdx.x] = a;
@@ -314,12 +323,13 @@ extern "C" int kmsr_conv3x3_smallci_unshuffle_fwd_f32(const kmsr_conv3x3_desc* d
                                                       float* out, float* chan_sums, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!d) return fail(KMSR_E_BADARG, "null descriptor");
     if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0) return fail(KMSR_E_BADARG, "bad conv shape");
-    if (!x || !w || !out || !chan_sums || !workspace) return fail(KMSR_E_BADARG, "null tensor pointer");
+    if (!x || !w || !out) return fail(KMSR_E_BADARG, "null tensor pointer");
+    if (chan_sums && !workspace) return fail(KMSR_E_BADARG, "small-Cin unshuffle conv: channel sums need the workspace");
     if (d->stride != 1 || d->pixel_shuffle || d->flags) return fail(KMSR_E_UNSUPPORTED, "small-Cin conv: stride 1, no pixel_shuffle, no flags");
     if (d->Cin > 8 || d->Cout > 64) return fail(KMSR_E_UNSUPPORTED, "small-Cin unshuffle conv serves Cin <= 8, Cout <= 64 (Cin=%d, Cout=%d)", d->Cin, d->Cout);
     if (d->H % 2 || d->W % 4 || reinterpret_cast<uintptr_t>(x) % 16) return fail(KMSR_E_UNSUPPORTED, "small-Cin unshuffle conv needs even H, W %% 4 == 0 and a 16-byte aligned input");
     if ((long long)d->H * d->W * 4 * 64 >= (1ll << 31)) return fail(KMSR_E_UNSUPPORTED, "small-Cin conv: H*W exceeds 2^23 pixels per plane");
-    if (workspace_bytes < kmsr_conv3x3_smallci_unshuffle_workspace_bytes(d)) return fail(KMSR_E_NOMEM, "small-Cin unshuffle conv: workspace too small");
+    if (chan_sums && workspace_bytes < kmsr_conv3x3_smallci_unshuffle_workspace_bytes(d)) return fail(KMSR_E_NOMEM, "small-Cin unshuffle conv: workspace too small");
     SmallCiParams p{};
     p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.relu = d->relu;
     p.tiles_x = ceil_div(d->W, QTW);
@@ -329,6 +339,16 @@ extern "C" int kmsr_conv3x3_smallci_unshuffle_fwd_f32(const kmsr_conv3x3_desc* d
     const int grid = smallci_grid(d);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     float* ws = static_cast<float*>(workspace);
+    if (!chan_sums) {           // store only: the caller has the sums from elsewhere (sr.UpTailFunction derives them from the input's border sums)
+        switch ((d->Cin + 1) / 2) {
+            case 1: conv3x3_smallci_kernel<1, true, 2, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+            case 2: conv3x3_smallci_kernel<2, true, 2, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+            case 3: conv3x3_smallci_kernel<3, true, 2, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+            default: conv3x3_smallci_kernel<4, true, 2, false><<<grid, 256, 0, stream>>>(x, w, bias, out, nullptr, p); break;
+        }
+        KMSR_HIP_CHECK(hipGetLastError());
+        return KMSR_OK;
+    }
     switch ((d->Cin + 1) / 2) {
         case 1: conv3x3_smallci_kernel<1, true><<<grid, 256, 0, stream>>>(x, w, bias, out, ws, p); break;
         case 2: conv3x3_smallci_kernel<2, true><<<grid, 256, 0, stream>>>(x, w, bias, out, ws, p); break;

@@ -238,9 +238,11 @@ def pixel_unshuffle2_sum(g):
     return gu, part.view(-1, 4 * C).sum(dim=0)
 
 
-def conv3x3_smallci_unshuffle(x, w, bias=None):
-    """conv3x3(x [N,Cin<=8,H,W], w [Cout<=64,Cin,3,3]) stored pixel-unshuffled -> (y [N,4 Cout,H/2,W/2], per-channel sums [4 Cout]) in one
-    launch (kmsr_conv3x3_smallci_unshuffle_fwd_f32): y[n, 4 co + 2 (i & 1) + (j & 1), i >> 1, j >> 1] = conv(x, w)[n, co, i, j]."""
+def conv3x3_smallci_unshuffle(x, w, bias=None, sums="kernel"):
+    """conv3x3(x [N,Cin<=8,H,W], w [Cout<=64,Cin,3,3]) stored pixel-unshuffled -> (y [N,4 Cout,H/2,W/2], per-channel sums [4 Cout])
+    (kmsr_conv3x3_smallci_unshuffle_fwd_f32): y[n, 4 co + 2 (i & 1) + (j & 1), i >> 1, j >> 1] = conv(x, w)[n, co, i, j].
+    sums="kernel": accumulated by the launch itself (fixed order); "closed_form": the launch only stores (2.5 instead of 4.7 ms at config 3)
+    and the sums come from unshuffled_conv_channel_sums (bias must be None); None: no sums."""
     lib = L.load()
     x = x.contiguous()
     w = w.detach().to(torch.float32).contiguous()
@@ -249,13 +251,53 @@ def conv3x3_smallci_unshuffle(x, w, bias=None):
     d = L.Conv3x3Desc()
     d.N, d.Cin, d.H, d.W, d.Cout, d.stride = N, Cin, H, W, Cout, 1
     y = torch.empty((N, 4 * Cout, H // 2, W // 2), device=x.device, dtype=torch.float32)
-    sums = torch.empty(4 * Cout, device=x.device, dtype=torch.float32)
+    if sums != "kernel":
+        assert sums in (None, "closed_form") and (sums is None or bias is None)
+        with torch.cuda.device(x.device):
+            L.check(lib.kmsr_conv3x3_smallci_unshuffle_fwd_f32(d, L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), None, None, 0, L.current_stream()))
+        return y, (unshuffled_conv_channel_sums(x, w) if sums else None)
+    csum = torch.empty(4 * Cout, device=x.device, dtype=torch.float32)
     nbytes = lib.kmsr_conv3x3_smallci_unshuffle_workspace_bytes(d)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
-        L.check(lib.kmsr_conv3x3_smallci_unshuffle_fwd_f32(d, L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), L.ptr(sums), L.ptr(ws), nbytes,
+        L.check(lib.kmsr_conv3x3_smallci_unshuffle_fwd_f32(d, L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), L.ptr(csum), L.ptr(ws), nbytes,
                                                            L.current_stream()))
-    return y, sums
+    return y, csum
+
+
+_PARITY_MAPS = {}
+
+
+def _parity_maps(H, W, device):
+    """A [3,2,H], B [3,2,W]: A[a, p, y'] = 1 when input row y' is reached through tap row a by an output row of parity p that lies inside the
+    image (output row y = y' - (a - 1)); the same for columns."""
+    key = (H, W, str(device))
+    if key not in _PARITY_MAPS:
+        def one(n):
+            m = torch.zeros(3, 2, n, dtype=torch.float32)
+            for a in range(3):
+                for yi in range(n):
+                    y = yi - (a - 1)
+                    if 0 <= y < n:
+                        m[a, y & 1, yi] = 1.0
+            return m
+        _PARITY_MAPS[key] = (one(H).to(device), one(W).to(device))
+    return _PARITY_MAPS[key]
+
+
+def unshuffled_conv_channel_sums(x, w):
+    """sums[4 co + 2 p + q] = sum over n and the output pixels (y, x) of parity (p, q) of conv3x3(x, w)[n, co, y, x] (zero padding 1, no bias),
+    WITHOUT the convolution: sum_p conv(x, w)[co, p] = sum_{ci,a,b} w[co,ci,a,b] * S[ci,a,b,p,q], where S is the sum of x[ci] over the input
+    pixels that tap (a, b) reaches from an in-image output pixel of that parity -- parity-class sums of x minus a border row / column.  One
+    reduction over the batch + two thin matrix products on the [Cin,H,W] image: 0.3 ms at config 3 where the sums inside the un-shuffling
+    conv cost 2.2 ms of spills.  fp32, fixed order (deterministic); differs from the in-kernel sums by re-association only."""
+    N, C, H, W = x.shape
+    A, B = _parity_maps(H, W, x.device)
+    G = x.sum(dim=0)                                                   # [C,H,W]
+    T = torch.matmul(G.reshape(C * H, W), B.reshape(6, W).t())         # [C*H, (b,q)]
+    S = torch.matmul(A.reshape(6, H), T.reshape(C, H, 6))              # [C, (a,p), (b,q)]
+    S = S.reshape(C, 3, 2, 3, 2)
+    return torch.einsum("ocab,capbq->opq", w.to(torch.float32), S).reshape(-1)
 
 
 def smallci_unshuffle_eligible(cin, cout, H, W):
@@ -417,9 +459,10 @@ class Conv3x3S2Function(torch.autograd.Function):
 class UpTailFunction(torch.autograd.Function):
     """out = tail(PixelShuffle2(up(h))) -- the last upsampler conv (F -> 4F, PixelShuffle fused into its store) and the tail conv
     (F -> bands) as ONE autograd node, so that the tail's data gradient can be written directly in the un-shuffled layout the up conv
-    takes as its output gradient (kmsr_conv3x3_smallci_unshuffle_fwd_f32, which also emits the up conv's bias gradient): the separate
-    pixel_unshuffle2_sum pass over the HR-sized gradient map (2 x 8.6 GB at config 3) disappears.  Same arithmetic as the two
-    Conv3x3Function nodes (the un-shuffle is a permutation; the bias-gradient sums are taken in a different, fixed order)."""
+    takes as its output gradient (kmsr_conv3x3_smallci_unshuffle_fwd_f32): the separate pixel_unshuffle2_sum pass over the HR-sized
+    gradient map (2 x 8.6 GB at config 3) disappears.  The up conv's bias gradient -- the per-channel sums of that map -- comes in closed form
+    from the loss gradient's parity / border sums (unshuffled_conv_channel_sums).  Same arithmetic as the two Conv3x3Function nodes (the
+    un-shuffle is a permutation; the bias-gradient sums are re-associated)."""
 
     @staticmethod
     def forward(ctx, h, w_up, b_up, w_tail, b_tail):
@@ -438,8 +481,9 @@ class UpTailFunction(torch.autograd.Function):
         dw_tail = conv3x3_wgrad(y2, g) if ctx.needs_input_grad[3] else None
         # tail data gradient = conv3x3(g, w') with w'[ci,co,u,v] = w_tail[co,ci,2-u,2-v], stored un-shuffled + its channel sums
         wt = w_tail.detach().flip(2, 3).transpose(0, 1).contiguous()
-        gu, s = conv3x3_smallci_unshuffle(g, wt)
-        db_up = s if ctx.has_bias[0] and ctx.needs_input_grad[2] else None
+        want_db_up = ctx.has_bias[0] and ctx.needs_input_grad[2]
+        gu, s = conv3x3_smallci_unshuffle(g, wt, sums="closed_form" if want_db_up else None)
+        db_up = s if want_db_up else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx, sx = Conv3x3Function._run(gu, w_up, None, False, flip=True, chan_sum=True)
@@ -658,11 +702,11 @@ class SRNet(nn.Module):
         self._caches = {}
         self.use_winograd = True    # inference path: Winograd MFMA kernels for the F->F / F->4F convs
         self.use_winograd4 = True   # inference path: F(4x4,3x3) for the aligned F->F / F->4F layers; False = F(2x2,3x3)
-        # training path: last upsampler conv + tail as one autograd node (UpTailFunction: the tail's data gradient is stored un-shuffled, no
-        # pixel_unshuffle2_sum pass).  OFF: correct (bit-identical gradients) and 2.5 ms SLOWER per config-3 step (91.1 vs 88.6 ms, A/B in one
-        # process, tools/time_train_ab.py) -- the un-shuffled store splits every 128-byte line of the 8.6 GB map into two 64-byte halves written by
-        # different instructions, which costs more than the separate pass saves.
-        self.fuse_up_tail_backward = False
+        # training path: last upsampler conv + tail as one autograd node (UpTailFunction: the tail's data gradient is stored un-shuffled by the
+        # small-Cin kernel itself -- lanes own the pixels of ONE sub-pixel plane, so the store is a full line -- and the up conv's bias gradient comes
+        # in closed form from the loss gradient's parity / border sums): no pixel_unshuffle2_sum pass over the 8.6 GB map.  85.5-85.9 vs 88.9 ms per
+        # config-3 step (A/B in one process, tools/time_train_ab.py; the first form of round 4 -- half-line stores, sums in registers -- was 2.5 ms slower).
+        self.fuse_up_tail_backward = True
         self.fuse_upsampler = True   # inference path, x4 only: up1/PS/up2/PS/tail (linear) run as one 5x5 conv + PS4 + the border-class frame launch
         #                              (same outputs, tests/test_fullsize_gpu.py; False = three conv3x3 launches)
         self._fused_up = _FusedUpsampler()

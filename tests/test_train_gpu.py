@@ -143,6 +143,15 @@ def test_smallci_unshuffle_equals_conv_then_unshuffle(N, Cin, H, W, Cout, gpu_de
     ref = want.double().sum(dim=(0, 2, 3))
     assert float((sums.double() - ref).abs().max()) <= 2e-6 * float(want.double().abs().sum(dim=(0, 2, 3)).max() + 1)
     assert torch.equal(conv3x3_smallci_unshuffle(x, w, bias=b)[1], sums)          # fixed-order reduction: run-to-run identical
+    # the store-only instance (chan_sums = NULL) writes the same tensor, and the closed form of the channel sums (parity / border sums of x
+    # times the weights: sr.unshuffled_conv_channel_sums) agrees with a float64 reduction of the bias-free convolution
+    got0, s0 = conv3x3_smallci_unshuffle(x, w, sums="closed_form")
+    want0 = torch.nn.functional.pixel_unshuffle(conv3x3(x, w, Cout, algo="smallci"), 2)
+    assert torch.equal(got0, want0)
+    ref0 = want0.double().sum(dim=(0, 2, 3))
+    assert float((s0.double() - ref0).abs().max()) <= 2e-6 * float(want0.double().abs().sum(dim=(0, 2, 3)).max() + 1)
+    assert torch.equal(conv3x3_smallci_unshuffle(x, w, sums="closed_form")[1], s0)
+    assert conv3x3_smallci_unshuffle(x, w, sums=None)[1] is None
 
 
 def test_up_tail_node_matches_separate_nodes(gpu_device):
