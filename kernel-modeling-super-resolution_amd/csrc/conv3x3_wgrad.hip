@@ -19,6 +19,7 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4v = __attribute__((ext_vector_type(4))) float;
 
+constexpr int kWgradSmallCo = 7;     // Cout <= 7: conv3x3_wgrad_smallco_kernel
 constexpr int WR = 2, WC = 32;            // pixel stage: rows x cols
 constexpr int WPX = WR * WC;              // 64 pixels per stage
 constexpr int XR = WR + 2, XC = WC + 2;   // halo tile of x
@@ -211,6 +212,10 @@ constexpr int SD_P = 9;                                                         
 constexpr int SX_F = WPX * PCH;                                                  // x stage [px][ci], pitch 65
 constexpr int SS_F = SX_F + SD_POS * SD_P;
 
+// N48 (round 4, Cout <= 5: at most 45 (co, tap) columns): v_mfma_f32_16x16x4_f32 tiles instead -- 4 ci blocks x 3 column blocks of 16, wave = one ci
+// block with its three accumulator tiles, K = 4 consecutive pixels of a row: 48 MFMAs of 32 cycles per stage and wave where the 32 x 32 tiling
+// (2 x 2 blocks, the second column block 13/32 used) spends 32 of 64 cycles; the kernel is bound by those cycles, not by reading x.
+template <bool N48>
 __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_smallco_kernel(const float* __restrict__ xg, const float* __restrict__ dyg,
                                                                        float* __restrict__ partial, WgradParams p) {
     __shared__ __attribute__((aligned(16))) float lds[2 * SS_F];
@@ -233,8 +238,21 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_smallco_kernel(const flo
     const unsigned HWb = (unsigned)HW * 4u;
     constexpr unsigned OOB = 0x80000000u;
     const bool wide = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(xg) & 15) == 0;       // block-uniform
-    float xr[16], dyr[NDYL];
-    auto load_stage = [&](int s) {
+    // the dy halo map of this thread is the same for every stage: (row, column) relative to the stage origin, channel byte offset, LDS slot
+    // (the divisions by the run-time Cout cost ~160 VALU per stage next to its 48 MFMAs when they sat inside the stage loop)
+    int dmap_y[NDYL], dmap_x[NDYL], dmap_l[NDYL];
+    unsigned dmap_c[NDYL];
+#pragma unroll
+    for (int j = 0; j < NDYL; ++j) {
+        const int e = tid + 256 * j;
+        const int pos = e / Cout, co = e - pos * Cout;
+        dmap_y[j] = pos / SD_COLS - 1;
+        dmap_x[j] = pos % SD_COLS - 1;
+        dmap_c[j] = (unsigned)co * HWb;
+        dmap_l[j] = e < SD_POS * Cout ? pos * SD_P + co : -1;
+    }
+    float xrA[16], dyrA[NDYL];
+    auto load_stage_to = [&](int s, float (&xr)[16], float (&dyr)[NDYL]) {
         const int n = s / p.n_stages, t = s % p.n_stages;
         const int y0 = (t / p.tiles_x) * WR, x0 = (t % p.tiles_x) * WC;
         const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xg + ((long long)n * p.Cin + cig * 64) * HW), 0,
@@ -257,14 +275,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_smallco_kernel(const flo
         }
 #pragma unroll
         for (int j = 0; j < NDYL; ++j) {
-            const int e = tid + 256 * j;
-            const int pos = e / Cout, co = e - pos * Cout;
-            const int y = y0 - 1 + pos / SD_COLS, x = x0 - 1 + pos % SD_COLS;
-            const bool ok = e < SD_POS * Cout && y >= 0 && y < H && x >= 0 && x < W;
-            dyr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, ok ? (unsigned)(y * W + x) * 4u + (unsigned)co * HWb : OOB, 0, 0));
+            const int y = y0 + dmap_y[j], x = x0 + dmap_x[j];
+            const bool ok = dmap_l[j] >= 0 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            dyr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, ok ? (unsigned)(y * W + x) * 4u + dmap_c[j] : OOB, 0, 0));
         }
     };
-    auto store_stage = [&](int b) {
+    auto store_stage_from = [&](int b, const float (&xr)[16], const float (&dyr)[NDYL]) {
         float* xl = lds + b * SS_F;
         float* dl = xl + SX_F;
         if (wide) {
@@ -277,13 +293,77 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_smallco_kernel(const flo
             for (int q = 0; q < 16; ++q) xl[dpx * PCH + 4 * q + sub] = xr[q];    // [px][ci]
         }
 #pragma unroll
-        for (int j = 0; j < NDYL; ++j) {
-            const int e = tid + 256 * j;
-            const int pos = e / Cout, co = e - pos * Cout;
-            if (e < SD_POS * Cout) dl[pos * SD_P + co] = dyr[j];                  // [pos][co]
-        }
+        for (int j = 0; j < NDYL; ++j)
+            if (dmap_l[j] >= 0) dl[dmap_l[j]] = dyr[j];                           // [pos][co]
     };
 
+    auto load_stage = [&](int s) { load_stage_to(s, xrA, dyrA); };
+    auto store_stage = [&](int b) { store_stage_from(b, xrA, dyrA); };
+    if constexpr (N48) {
+        using f32x4a = __attribute__((ext_vector_type(4))) float;
+        const int l16 = lane & 15, kq = lane >> 4;
+        int boffs3[3];
+#pragma unroll
+        for (int nbk = 0; nbk < 3; ++nbk) {
+            const int ncol = 16 * nbk + l16;
+            const bool nok = ncol < Cout * 9;
+            const int nco = nok ? ncol / 9 : 0, ntap = nok ? ncol % 9 : 0;
+            boffs3[nbk] = ((2 - ntap / 3) * SD_COLS + (2 - ntap % 3)) * SD_P + nco + kq * SD_P;   // + (r * SD_COLS + 4 c4) * SD_P; k = pixel of the quad
+        }
+        f32x4a acc3[3];
+#pragma unroll
+        for (int nbk = 0; nbk < 3; ++nbk) acc3[nbk] = f32x4a{0.f, 0.f, 0.f, 0.f};
+        // two register staging sets: stage s + 2 nblk is requested while stage s is multiplied and written to LDS during stage s + nblk -- one
+        // stage of MFMAs (48 x 32 cycles = 0.7 us) does not cover an HBM round trip
+        float xrB[16], dyrB[NDYL];
+        auto products = [&](int b) {
+            const float* xl = lds + b * SS_F;
+            const float* ap = xl + kq * PCH + 16 * wv + l16;                      // A[m = ci of block wv][k = pixel of the quad]; + px * PCH
+            const float* bq = xl + SX_F;
+#pragma unroll
+            for (int r = 0; r < WR; ++r) {
+#pragma unroll
+                for (int c4 = 0; c4 < WC / 4; ++c4) {
+                    const float a = ap[(r * WC + 4 * c4) * PCH];
+#pragma unroll
+                    for (int nbk = 0; nbk < 3; ++nbk) {
+                        // columns past Cout * 9 read column 0's values: a column of D depends on its own B column only, and the reduction
+                        // never reads those columns -- no select on the port the MFMA shares
+                        const float bv = bq[boffs3[nbk] + (r * SD_COLS + 4 * c4) * SD_P];
+                        acc3[nbk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc3[nbk], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        int s = blockIdx.x;
+        const int step = p.nblk;
+        if (s < total) {
+            load_stage_to(s, xrA, dyrA);
+            if (s + step < total) load_stage_to(s + step, xrB, dyrB);
+            store_stage_from(0, xrA, dyrA);
+        }
+        __syncthreads();
+        for (; s < total; s += 2 * step) {
+            {   // even stage of the pair: LDS buffer 0; request s + 2 step into set A, write s + step from set B
+                if (s + 2 * step < total) load_stage_to(s + 2 * step, xrA, dyrA);
+                products(0);
+                if (s + step < total) store_stage_from(1, xrB, dyrB);
+                __syncthreads();
+            }
+            if (s + step < total) {
+                if (s + 3 * step < total) load_stage_to(s + 3 * step, xrB, dyrB);
+                products(1);
+                if (s + 2 * step < total) store_stage_from(0, xrA, dyrA);
+                __syncthreads();
+            }
+        }
+        // D lane l: column n = l & 15 of block nbk, rows ci = 16 wv + 4 (l >> 4) + reg
+        float* out = partial + ((long long)cig * p.nblk + blockIdx.x) * (64 * 64);
+#pragma unroll
+        for (int nbk = 0; nbk < 3; ++nbk)
+            *reinterpret_cast<f32x4a*>(out + (16 * nbk + l16) * 64 + 16 * wv + 4 * kq) = acc3[nbk];
+        return;
+    }
     // this lane's B column: n = 32 nb + l32 = co * 9 + tap; the dy position of x pixel (r, c) is (r + 2 - u, c + 2 - v) in the halo tile
     const int ncol = 32 * nb + l32;
     const bool nok = ncol < Cout * 9;
@@ -346,11 +426,11 @@ __global__ void reduce_partials_smallco_kernel(const float* __restrict__ partial
     dw[((long long)co * Cin + ci) * 9 + tap] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
 }
 
-constexpr int kWgradSmallCo = 7;
 
 int wgrad_blocks(const kmsr_conv3x3_desc* d) {
     const long long stages = (long long)d->N * ceil_div(d->H, WR) * ceil_div(d->W, WC);
-    return (int)std::min<long long>(stages, 512);   // two persistent workgroups per CU (52 KB of LDS each, 2 waves per SIMD)
+    // two persistent workgroups per CU (52 KB of LDS each, 2 waves per SIMD); the small-Cout kernel (43 KB, 104 VGPRs) runs three
+    return (int)std::min<long long>(stages, d->Cout <= kWgradSmallCo ? 768 : 512);
 }
 
 }  // namespace
@@ -397,7 +477,10 @@ extern "C" int kmsr_conv3x3_wgrad_f32(const kmsr_conv3x3_desc* d, const float* x
     p.nblk = wgrad_blocks(d);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (d->Cout <= kWgradSmallCo) {
-        conv3x3_wgrad_smallco_kernel<<<dim3(p.nblk, p.cigs), 256, 0, stream>>>(x, dy, static_cast<float*>(workspace), p);
+        if (d->Cout * 9 <= 48)
+            conv3x3_wgrad_smallco_kernel<true><<<dim3(p.nblk, p.cigs), 256, 0, stream>>>(x, dy, static_cast<float*>(workspace), p);
+        else
+            conv3x3_wgrad_smallco_kernel<false><<<dim3(p.nblk, p.cigs), 256, 0, stream>>>(x, dy, static_cast<float*>(workspace), p);
         KMSR_HIP_CHECK(hipGetLastError());
         const int tot = d->Cout * d->Cin * 9;
         reduce_partials_smallco_kernel<<<ceil_div(tot, 256), 256, 0, stream>>>(static_cast<const float*>(workspace), dw, d->Cin,
