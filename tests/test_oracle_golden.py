@@ -305,6 +305,23 @@ def test_make_golden_reproduces_fixtures(tmp_path):
             assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), f"{f}:{k} differs"
 
 
+def test_unshuffled_conv_channel_sums_closed_form_cpu():
+    """sr.unshuffled_conv_channel_sums (round 4: the F -> 4F layer's bias gradient without a pass over the HR-sized gradient map): the per-(channel,
+    row parity, column parity) sums of a zero-padded 3x3 convolution from parity / border sums of its INPUT, against a float64 convolution --
+    even sizes, several images, the borders that drop a row / column per tap."""
+    import torch
+    from kmsr_amd.sr import unshuffled_conv_channel_sums
+    g = torch.Generator().manual_seed(11)
+    for (N, C, H, W, Co) in ((3, 5, 12, 16, 7), (1, 2, 2, 4, 3), (2, 5, 6, 8, 64)):
+        x = torch.randn(N, C, H, W, generator=g)
+        w = torch.randn(Co, C, 3, 3, generator=g)
+        y = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+        ref = torch.stack([y[:, :, p::2, q::2].sum((0, 2, 3)) for p in range(2) for q in range(2)], 1).reshape(-1)      # [4 co + 2 p + q]
+        got = unshuffled_conv_channel_sums(x, w)
+        assert got.shape == (4 * Co,)
+        assert float((got.double() - ref).abs().max()) <= 2e-6 * float(y.abs().sum((0, 2, 3)).max()), (N, C, H, W, Co)
+
+
 def test_stride2_backward_index_maps_cpu():
     """Host logic of sr.Conv3x3S2Function (round 4), checked with stock torch on the CPU: the data gradient of a stride-2 pad-1 conv is
     PixelShuffle2 of a stride-1 conv of the output gradient with the re-indexed weights s2_dgrad_weights(w), and its weight gradient is a
