@@ -8,11 +8,15 @@ torch.cuda.set_device(0)
 g = torch.Generator().manual_seed(0)
 N, C, H, W = 16, 64, 256, 256
 x = torch.randn(N, C, H, W, generator=g).cuda()
+if os.environ.get("KMSR_ZERO_INPUT"):       # clock probe: same launch, same traffic, all-zero input
+    x.zero_()
 w = (torch.randn(C, C, 3, 3, generator=g) / 24).cuda()
 b = torch.randn(C, generator=g).cuda()
 out = torch.empty_like(x)
 ref = torch.nn.functional.conv2d(x[:1].double(), w.double(), b.double(), padding=1)
 r = torch.randn(N, C, H, W, generator=g).cuda()
+if os.environ.get("KMSR_ZERO_INPUT"):
+    r.zero_()
 for algo in (sys.argv[1:] or ("winograd_vreg", "winograd4")):
     pw = pack_for(algo, w)
     for name, kw in (("relu", dict(relu=True)), ("residual", dict(residual=r)), ("relu", dict(relu=True))):
