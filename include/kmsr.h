@@ -186,6 +186,9 @@ int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float
                          const float* bias,      /* [Cout] or NULL                                  */
                          const float* residual,  /* out-shaped or NULL (not with pixel_shuffle)      */
                          float* out, void* stream);
+/* Limits: stride 1 or 2; per image Cin * H * W < 2^31 elements and 8 * H * W * 4 < 2^32 bytes (round 4: input tiles are staged by buffer
+ * loads whose 32-bit byte offsets span an 8-channel chunk; padding and channels past Cin are out-of-range offsets = zeros) -> otherwise
+ * KMSR_E_UNSUPPORTED.  Stride 2 with W % 4 == 0 and a 16-byte aligned x takes the instance that stages 16-byte pieces; same results. */
 
 /* Backward of the fused PixelShuffle(2) store: g [N,C,2H,2W] (gradient in the shuffled layout) -> gu [N,4C,H,W] with
  * gu[n,4c+2i+j,y,x] = g[n,c,2y+i,2x+j], plus per-channel partial sums partials[N * ceil(H/32)][4C] (add them over the first

@@ -191,7 +191,11 @@ class GradBucket:
             p.grad = v
         if dst:
             with torch.no_grad():
-                torch._foreach_copy_(dst, src)
+                if hasattr(torch, "_foreach_copy_"):
+                    torch._foreach_copy_(dst, src)          # one multi-tensor launch
+                else:
+                    for v, g in zip(dst, src):
+                        v.copy_(g)
         self._gathered[k] = True
 
     def _launch(self, k):
