@@ -517,7 +517,7 @@ class TrainWorkload:
         self.taps_ready = True
         self.step_no += 1
         self.bucket.zero()                   # arms the overlap hooks: the upper half of the gradient is all-reduced (async, RCCL's
-        loss = torch.nn.functional.l1_loss(self.net(self.lr), self.hr)     # own stream) while backward still runs the lower layers
+        loss = kmsr_amd.sr.l1_loss(self.net(self.lr), self.hr)             # own stream) while backward still runs the lower layers
         loss.backward()
         self.bucket.finish()                 # launches the rest, waits, scales by 1/world
         self.opt.step()

@@ -190,6 +190,15 @@ int kmsr_conv3x3_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float
  * loads whose 32-bit byte offsets span an 8-channel chunk; padding and channels past Cin are out-of-range offsets = zeros) -> otherwise
  * KMSR_E_UNSUPPORTED.  Stride 2 with W % 4 == 0 and a 16-byte aligned x takes the instance that stages 16-byte pieces; same results. */
 
+/* L1 loss of the SR training step (build-defined, the reference has no SR model or loss): *loss = mean |a - b| over n floats and,
+ * when grad != NULL, grad[i] = sign(a[i] - b[i]) / n -- the gradient w.r.t. a for an upstream gradient of 1 -- in ONE pass over a and b
+ * (torch's l1_loss + autograd: five passes).  Fixed-order reduction (deterministic).  workspace: kmsr_l1_loss_workspace_floats() floats.
+ * a, b, grad 16-byte aligned.  kmsr_scale_by_device_scalar_f32: x *= *scale in place unless *scale == 1 (the upstream gradient of
+ * loss.backward() lives on the device; no host sync). */
+size_t kmsr_l1_loss_workspace_floats(void);
+int kmsr_l1_loss_f32(const float* a, const float* b, int64_t n, float* loss, float* grad, float* workspace, void* stream);
+int kmsr_scale_by_device_scalar_f32(float* x, int64_t n, const float* scale, void* stream);
+
 /* Backward of the fused PixelShuffle(2) store: g [N,C,2H,2W] (gradient in the shuffled layout) -> gu [N,4C,H,W] with
  * gu[n,4c+2i+j,y,x] = g[n,c,2y+i,2x+j], plus per-channel partial sums partials[N * ceil(H/32)][4C] (add them over the first
  * axis for the bias gradient sum_{n,y,x} gu; fixed order).  One pass instead of permute-copy + reduction.  W % 4 == 0. */

@@ -78,6 +78,9 @@ SYMBOLS = {
     "kmsr_conv3x3_fwd_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "kmsr_pixel_unshuffle2_sum_partials": (_sz, [_i32, _i32, _i32]),
     "kmsr_pixel_unshuffle2_sum_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "kmsr_l1_loss_workspace_floats": (C.c_size_t, []),
+    "kmsr_l1_loss_f32": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _vp]),
+    "kmsr_scale_by_device_scalar_f32": (C.c_int, [_vp, C.c_int64, _vp, _vp]),
     "kmsr_conv3x3_dgrad_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp]),
     "kmsr_conv3x3_pixelshuffle_fwd_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp]),
     "kmsr_conv3x3_pixelshuffle_fwd_bf16": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp]),

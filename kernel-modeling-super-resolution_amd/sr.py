@@ -319,6 +319,42 @@ def _tag_sum(t, sums):
     return t
 
 
+class L1LossFunction(torch.autograd.Function):
+    """mean |a - b| with the gradient w.r.t. a produced by the forward's own pass (kmsr_l1_loss_f32: value + sign(a - b) / n in one launch over
+    the two tensors; torch's l1_loss and its backward walk them five times).  b gets no gradient (the target).  backward rescales the stored
+    gradient in place by the upstream gradient, read on the device (kmsr_scale_by_device_scalar_f32: a no-op launch when it is 1)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = L.load()
+        L.require_gpu()
+        assert a.shape == b.shape and a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_cuda and b.is_cuda
+        a, b = a.contiguous(), b.contiguous()
+        loss = torch.empty((), device=a.device, dtype=torch.float32)
+        grad = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(lib.kmsr_l1_loss_workspace_floats(), device=a.device, dtype=torch.float32)
+        with torch.cuda.device(a.device):
+            L.check(lib.kmsr_l1_loss_f32(L.ptr(a), L.ptr(b), a.numel(), L.ptr(loss), L.ptr(grad), L.ptr(ws), L.current_stream()))
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, ctx.grad = ctx.grad, None
+        if grad is None:
+            return None, None
+        lib = L.load()
+        g = g.detach().to(torch.float32).contiguous()
+        with torch.cuda.device(grad.device):
+            L.check(lib.kmsr_scale_by_device_scalar_f32(L.ptr(grad), grad.numel(), L.ptr(g), L.current_stream()))
+        return grad, None
+
+
+def l1_loss(a, b):
+    """torch.nn.functional.l1_loss(a, b) (mean reduction, gradient to `a` only) on the fused HIP kernel."""
+    return L1LossFunction.apply(a, b)
+
+
 class Conv3x3Function(torch.autograd.Function):
     """y = [relu](conv3x3(x, w) + b) with the HIP kernels in both directions (stride 1):
     forward  kmsr_conv3x3[_wino|_winov]_fwd_f32, backward  dx = conv3x3(g, flip-transposed w) (same kernels), dw =

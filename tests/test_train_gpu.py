@@ -197,3 +197,31 @@ def test_conv3x3_stride2_function_vs_torch(N, Cin, H, W, Cout, gpu_device):
     yc.backward(gy.cuda())
     assert yc.shape == yr.shape and _rel(yc, yr) < 2e-5
     assert _rel(xc.grad, xr.grad) < 2e-5 and _rel(wc.grad, wr.grad) < 2e-5 and _rel(bc.grad, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 64, 64), (1, 3, 7, 11), (3, 1, 1, 1), (1, 5, 256, 1024)])
+def test_l1_loss_value_and_gradient_vs_torch(shape, gpu_device):
+    """kmsr_l1_loss_f32 (value and sign(a - b) / n in one pass; the SR training step's loss) against torch.nn.functional.l1_loss and its
+    autograd: value to fp32 summation rounding, gradient exactly; an upstream factor goes through kmsr_scale_by_device_scalar_f32; exact zeros
+    of a - b get a zero gradient; deterministic; the target gets no gradient."""
+    from kmsr_amd.sr import l1_loss
+    g = torch.Generator().manual_seed(sum(shape))
+    a = torch.randn(*shape, generator=g).cuda().requires_grad_()
+    b = torch.randn(*shape, generator=g).cuda()
+    with torch.no_grad():
+        b.view(-1)[::5] = a.detach().view(-1)[::5]                 # exact zeros of the difference
+    ref_a = a.detach().clone().requires_grad_()
+    ref = torch.nn.functional.l1_loss(ref_a, b)
+    got = l1_loss(a, b)
+    assert got.shape == () and abs(float(got) - float(ref)) <= 2e-6 * float(ref) + 1e-12
+    ref.backward()
+    got.backward()
+    assert torch.equal(a.grad, ref_a.grad)                          # sign(a - b) / n, bit for bit
+    assert float(a.grad.view(-1)[::5].abs().max()) == 0.0
+    a.grad, ref_a.grad = None, None
+    got2 = l1_loss(a, b)
+    (2.5 * got2).backward()                                          # the upstream factor is applied on the device
+    (2.5 * torch.nn.functional.l1_loss(ref_a, b)).backward()
+    assert torch.equal(got2, got)
+    assert float((a.grad - ref_a.grad).abs().max()) <= 1e-6 * float(ref_a.grad.abs().max())
+    assert l1_loss(a.detach(), b).requires_grad is False
