@@ -5,6 +5,8 @@ import torch
 from kmsr_amd.sr_bf16 import conv3x3_bf16, pack_conv3x3_weight_bf16, resblock_bf16
 H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 x = torch.randn(1, H, W, 64, device="cuda").to(torch.bfloat16)
+if os.environ.get("KMSR_ZERO_INPUT"):       # clock probe: same launches, all-zero activations
+    x.zero_()
 w1, w2 = torch.randn(64, 64, 3, 3, device="cuda") / 24, torch.randn(64, 64, 3, 3, device="cuda") / 24
 b1, b2 = torch.randn(64, device="cuda"), torch.randn(64, device="cuda")
 p1, p2 = pack_conv3x3_weight_bf16(w1, 64, 64), pack_conv3x3_weight_bf16(w2, 64, 64)
