@@ -90,6 +90,37 @@ def _worker(rank, world, port, q):
     torch.nn.functional.mse_loss(net(x_all[sl]), y_all[sl]).backward()
     assert bucket.launched() == 0
     bucket.finish()
+    # (3f) round 4: gradients are taken over from autograd and gathered into the flat buffer per slice.  A parameter no gradient reaches
+    #      (unused branch) must read as zeros in the buffer, p.grad must be the buffer's view again after finish(), and stale values of
+    #      the previous step must not survive
+    class _Two(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.unused, self.b = torch.nn.Linear(3, 3), torch.nn.Linear(3, 3), torch.nn.Linear(3, 2)
+
+        def forward(self, x):
+            return self.b(torch.relu(self.a(x)))
+    torch.manual_seed(1)
+    two = _Two()
+    kd.broadcast_parameters(two, src=0)
+    b2 = kd.GradBucket(two.parameters())
+    xs = torch.randn(4, 3, generator=torch.Generator().manual_seed(5))
+    for rep in range(2):
+        b2.flat.fill_(123.0)                        # stale content
+        b2.zero()
+        assert all(p_.grad is None for p_ in two.parameters())
+        two(xs[rank * 2:rank * 2 + 2]).square().mean().backward()
+        b2.finish()
+        for p_, v_ in zip(b2.params, b2._views):
+            assert p_.grad.data_ptr() == v_.data_ptr()
+        assert float(two.unused.weight.grad.abs().max()) == 0.0 and float(two.unused.bias.grad.abs().max()) == 0.0
+        assert kd.ranks_agree(b2.flat) == (world, True)
+    ref2 = _Two()
+    ref2.load_state_dict(two.state_dict())
+    ref2(xs).square().mean().backward()
+    for a, b in zip(two.parameters(), ref2.parameters()):
+        if b.grad is not None:
+            assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-7)
     # (3e) ragged shards: explicit global sample offsets from one all_gather; the equal-batch guard trips on every rank
     assert kd.batch_offsets(3 + rank) == (0 if rank == 0 else 3, 7)
     kd.assert_equal_batch(4)
