@@ -315,6 +315,10 @@ int kmsr_conv3x3_winov_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const
 size_t kmsr_conv3x3_wino4_packed_weight_floats(int32_t Cin, int32_t Cout);
 int kmsr_conv3x3_wino4_pack_weights_f32(const float* w /* [Cout,Cin,3,3] */, int32_t Cin, int32_t Cout, float* packed,
                                         void* stream);
+/* transpose_flip = 1 (round 4): pack the DATA-GRADIENT convolution of the forward layer w [Cout,Cin,3,3] (w'[ci,co,u,v] = w[co,ci,2-u,2-v]; the
+ * packed convolution runs Cout -> Cin channels: size the buffer with kmsr_conv3x3_wino4_packed_weight_floats(Cout, Cin)) in the pack launch
+ * itself -- same convention as kmsr_conv3x3_pack_weights_f32.  transpose_flip = 0 is kmsr_conv3x3_wino4_pack_weights_f32. */
+int kmsr_conv3x3_wino4_pack_weights_ex_f32(const float* w, int32_t Cin, int32_t Cout, int32_t transpose_flip, float* packed, void* stream);
 int kmsr_conv3x3_wino4_fwd_f32(const kmsr_conv3x3_desc* d, const float* x, const float* packed_w, const float* bias,
                                const float* residual, float* out, void* stream);
 /* The same kernel with the F(2x2) kernel's other epilogues: d->pixel_shuffle (fused PixelShuffle(2), no residual), and the training

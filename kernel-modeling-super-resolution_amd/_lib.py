@@ -111,6 +111,7 @@ SYMBOLS = {
     "kmsr_conv3x3_winov_fwd_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "kmsr_conv3x3_wino4_packed_weight_floats": (_sz, [_i32, _i32]),
     "kmsr_conv3x3_wino4_pack_weights_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "kmsr_conv3x3_wino4_pack_weights_ex_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "kmsr_conv3x3_wino4_fwd_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "kmsr_conv3x3_wino4_chan_sum_floats": (_sz, [C.POINTER(Conv3x3Desc)]),
     "kmsr_conv3x3_wino4_fwd_ex_f32": (C.c_int, [C.POINTER(Conv3x3Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -80,7 +80,10 @@ enum { W4_PLAIN = 0, W4_PS = 1, W4_TRAIN = 2 };
 // packed[cg][step][hh][grp][cbi][lane][jj] = (G g G^T)[xi = 4 grp + jj]  for
 // (co, ci) = (cg*64 + hh*32 + cbi*16 + (lane & 15), step*4 + (lane >> 4)), zero padded; xi = 6 i + j.
 // G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]; computed in double, rounded once.
-__global__ void wino4_pack_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ packed, int nsteps,
+// tf (round 4): w is the FORWARD layer's [Cin][Cout][3][3] tensor and the packed convolution is its data gradient, w'[co][ci][u][v] =
+// w[ci][co][2-u][2-v] -- the flip + transpose + copy launches torch needed per layer and step are an index swap here (Cin / Cout below are
+// those of the PACKED convolution)
+__global__ void wino4_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int tf, float* __restrict__ packed, int nsteps,
                                   long long total) {
     const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
@@ -98,9 +101,9 @@ __global__ void wino4_pack_kernel(const float* __restrict__ w, int Cin, int Cout
         const int cog = cg * QCO + hh * 32 + cbi * 16 + (lane & 15), cig = step * QCK + (lane >> 4);
         double v = 0.0;
         if (cog < Cout && cig < Cin) {
-            const float* g = w + ((long long)cog * Cin + cig) * 9;
+            const float* g = tf ? w + ((long long)cig * Cout + cog) * 9 : w + ((long long)cog * Cin + cig) * 9;
             for (int a = 0; a < 3; ++a)
-                for (int b = 0; b < 3; ++b) v += G[i][a] * (double)g[a * 3 + b] * G[j][b];
+                for (int b = 0; b < 3; ++b) v += G[i][a] * (double)g[tf ? (2 - a) * 3 + (2 - b) : a * 3 + b] * G[j][b];
         }
         packed[idx] = (float)v;
     }
@@ -607,14 +610,25 @@ extern "C" size_t kmsr_conv3x3_wino4_packed_weight_floats(int32_t Cin, int32_t C
     return (size_t)ceil_div(Cout, QCO) * ceil_div(Cin, QCK) * QUF;
 }
 
-extern "C" int kmsr_conv3x3_wino4_pack_weights_f32(const float* w, int32_t Cin, int32_t Cout, float* packed, void* stream) {
+static int wino4_pack(const float* w, int32_t Cin, int32_t Cout, int tf, float* packed, void* stream) {
     if (!w || !packed || Cin <= 0 || Cout <= 0) return fail(KMSR_E_BADARG, "winograd-4x4 pack: bad argument");
     const int nsteps = ceil_div(Cin, QCK);
     const long long total = (long long)ceil_div(Cout, QCO) * nsteps * QUF;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-    wino4_pack_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(w, Cin, Cout, packed, nsteps, total);
+    wino4_pack_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(w, Cin, Cout, tf, packed, nsteps, total);
     KMSR_HIP_CHECK(hipGetLastError());
     return KMSR_OK;
+}
+
+extern "C" int kmsr_conv3x3_wino4_pack_weights_f32(const float* w, int32_t Cin, int32_t Cout, float* packed, void* stream) {
+    return wino4_pack(w, Cin, Cout, 0, packed, stream);
+}
+
+// transpose_flip = 1: w is [Cout][Cin][3][3] of the forward layer; packs its data-gradient convolution (Cout -> Cin channels) -- same
+// convention as kmsr_conv3x3_pack_weights_f32: Cin / Cout are w's own dimensions, the packed convolution's are swapped
+extern "C" int kmsr_conv3x3_wino4_pack_weights_ex_f32(const float* w, int32_t Cin, int32_t Cout, int32_t transpose_flip, float* packed, void* stream) {
+    if (transpose_flip) return wino4_pack(w, Cout, Cin, 1, packed, stream);
+    return wino4_pack(w, Cin, Cout, 0, packed, stream);
 }
 
 extern "C" size_t kmsr_conv3x3_wino4_chan_sum_floats(const kmsr_conv3x3_desc* d) {

@@ -57,16 +57,19 @@ def pack_conv3x3_weight_wino_vreg(weight):
     return packed
 
 
-def pack_conv3x3_weight_wino4(weight):
+def pack_conv3x3_weight_wino4(weight, transpose_flip=False):
     """[Cout,Cin,3,3] -> G g G^T (6x6 points, F(4x4,3x3)) packed for conv3x3(..., algo="winograd4"): per 4-channel step the 36 KB a
-    workgroup multiplies, lane-linear per wave and group of 4 transform points (one buffer_load_dwordx4 per lane and group)."""
+    workgroup multiplies, lane-linear per wave and group of 4 transform points (one buffer_load_dwordx4 per lane and group).
+    transpose_flip=True packs the layer's DATA-GRADIENT convolution (Cout -> Cin channels, w'[ci,co,u,v] = w[co,ci,2-u,2-v]) in the same
+    launch -- no flip / transpose / copy passes (kmsr_conv3x3_wino4_pack_weights_ex_f32)."""
     lib = L.load()
     assert weight.is_cuda and weight.dtype == torch.float32 and weight.ndim == 4 and weight.shape[2:] == (3, 3)
     w = weight.detach().contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
-    packed = torch.empty(lib.kmsr_conv3x3_wino4_packed_weight_floats(Cin, Cout), device=w.device, dtype=torch.float32)
+    pin, pout = (Cout, Cin) if transpose_flip else (Cin, Cout)
+    packed = torch.empty(lib.kmsr_conv3x3_wino4_packed_weight_floats(pin, pout), device=w.device, dtype=torch.float32)
     with torch.cuda.device(w.device):
-        L.check(lib.kmsr_conv3x3_wino4_pack_weights_f32(L.ptr(w), Cin, Cout, L.ptr(packed), L.current_stream()))
+        L.check(lib.kmsr_conv3x3_wino4_pack_weights_ex_f32(L.ptr(w), Cin, Cout, 1 if transpose_flip else 0, L.ptr(packed), L.current_stream()))
     return packed
 
 
@@ -213,9 +216,12 @@ class _TrainPacks:
         if ent is not None and ent[0] == w._version and ent[1]() is w:
             return ent[2]
         src = w.detach()
-        if flip:                                       # data gradient = the same convolution with w'[ci,co,u,v] = w[co,ci,2-u,2-v]
-            src = src.flip(2, 3).transpose(0, 1).contiguous()
-        packed = pack_for(algo, src)
+        if flip and algo == "winograd4":               # the pack launch reads the forward tensor through the flipped / transposed index map
+            packed = pack_conv3x3_weight_wino4(src, transpose_flip=True)
+        else:
+            if flip:                                   # data gradient = the same convolution with w'[ci,co,u,v] = w[co,ci,2-u,2-v]
+                src = src.flip(2, 3).transpose(0, 1).contiguous()
+            packed = pack_for(algo, src)
         if len(cls._store) > 4096:                     # parameters that went away (their storage may be reused under another key)
             cls._store = {k: e for k, e in cls._store.items() if e[1]() is not None}
         cls._store[key] = (w._version, weakref.ref(w), packed)

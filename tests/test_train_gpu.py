@@ -225,3 +225,15 @@ def test_l1_loss_value_and_gradient_vs_torch(shape, gpu_device):
     assert torch.equal(got2, got)
     assert float((a.grad - ref_a.grad).abs().max()) <= 1e-6 * float(ref_a.grad.abs().max())
     assert l1_loss(a.detach(), b).requires_grad is False
+
+
+@pytest.mark.parametrize("Cout,Cin", [(64, 64), (256, 64), (64, 256), (40, 24), (5, 64)])
+def test_wino4_pack_transpose_flip_is_the_pack_of_the_flipped_tensor(Cout, Cin, gpu_device):
+    """kmsr_conv3x3_wino4_pack_weights_ex_f32(transpose_flip=1) (round 4: the data-gradient weights of a layer packed straight from its forward
+    tensor) is bit-identical to flipping / transposing the tensor with torch and packing the result."""
+    from kmsr_amd.sr import pack_conv3x3_weight_wino4
+    w = torch.randn(Cout, Cin, 3, 3, generator=torch.Generator().manual_seed(Cout + Cin)).cuda()
+    want = pack_conv3x3_weight_wino4(w.flip(2, 3).transpose(0, 1).contiguous())
+    got = pack_conv3x3_weight_wino4(w, transpose_flip=True)
+    assert got.shape == want.shape and torch.equal(got, want)
+    assert torch.equal(pack_conv3x3_weight_wino4(w, transpose_flip=False), pack_conv3x3_weight_wino4(w))
