@@ -103,7 +103,7 @@ typedef struct kmsr_degrade_desc {
 
 /* LR size for a descriptor (pure host arithmetic). */
 int kmsr_degrade_out_shape(const kmsr_degrade_desc* d, int32_t* h, int32_t* w);
-/* Bytes of device workspace kmsr_degrade_f32 needs (effective tap tables). */
+/* Bytes of device workspace kmsr_degrade_f32 needs (the effective tap table and its row-reversed copy). */
 size_t kmsr_degrade_workspace_bytes(const kmsr_degrade_desc* d);
 /* 1 if this descriptor is served by the row-streaming fast kernel, 0 if by the generic kernel. */
 int kmsr_degrade_uses_fast_path(const kmsr_degrade_desc* d, const void* hr);

@@ -52,6 +52,7 @@ struct DegradeParams {
     int pad_zero;
     int noise_mode;
     int rows_per_chunk, n_chunks, n_strips, n_units, n_blocks;
+    int n_tap_rows;             // (bank row, band) entries of the tap table; its row-reversed copy starts n_tap_rows * TY * TXP floats in
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -73,6 +74,9 @@ __global__ void prepare_taps_kernel(const float* __restrict__ kernels, int kh, i
         kn[i] = div ? (double)(k[i] / (float)ksum) : (double)k[i];  // fp32 division as in C_30:97
     __syncthreads();
     float* t = taps + (size_t)blockIdx.x * TY * TXP;
+    // second copy with the tap ROWS reversed, behind the table ([gridDim.x][TY][TXP] again): the row-streaming kernel's bottom-up
+    // chunks read it, so that "tap row al" is base + a literal offset for both walking directions
+    float* tr = taps + ((size_t)gridDim.x + blockIdx.x) * TY * TXP;
     for (int e = threadIdx.x; e < TY * TXP; e += blockDim.x) {
         const int a = e / TXP, b = e % TXP;
         double v = 0.0;
@@ -89,6 +93,7 @@ __global__ void prepare_taps_kernel(const float* __restrict__ kernels, int kh, i
             }
         }
         t[e] = (float)v;
+        tr[(TY - 1 - a) * TXP + b] = (float)v;
     }
 }
 
@@ -291,7 +296,6 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
     const bool up = (chunk & 1) != 0;
     const int s_top = F * (i1 - 1) + TY - 1;                    // bottom-most shifted row of the chunk
     const int sl_last = F * (nrows - 1) + TY - 1;               // last local row that carries a tap
-    const int sl_end = F * (nrows - 1 + TYB - 1) + F - 1;       // end of the group that retires the last local output row
     // local rows that are actually staged form one contiguous range [sa, sb]: zero padding skips out-of-image rows
     int sa = 0, sb = sl_last;
     if (pad_zero) {
@@ -299,11 +303,11 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
         else { sa = max(0, s_top - (H - 1 + PH)); sb = min(sl_last, s_top - PH); }
     }
 
-    auto issue_row = [&](int sl) {   // sl wave-uniform, sa <= sl <= sb
+    auto issue_row = [&](int sl, int slot_off) {   // sl wave-uniform, sa <= sl <= sb; slot_off = ((sl - sa) % R) * ROWF (kept as a running offset)
         const int s = up ? s_top - sl : F * i0 + sl;
         const int r = min(max(s - PH, 0), H - 1);               // replicate padding clamps the row
         const float* __restrict__ rp = img + (long long)r * p.sH + col0;
-        float* slot = ring + ((sl - sa) % R) * ROWF;
+        float* slot = ring + slot_off;
 #pragma unroll
         for (int t = 0; t < NLD; ++t) {
             if (live[t]) {                                      // wave-uniform: exactly one VMEM instruction
@@ -316,92 +320,140 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
 
 #pragma unroll
     for (int k = 0; k < R - 1; ++k)
-        if (sa + k <= sb) issue_row(sa + k);
+        if (sa + k <= sb) issue_row(sa + k, k * ROWF);
 
-    int gl = 0, q = 0;                                          // local group (= local output row being opened), phase
-    for (int sl = 0; sl <= sl_end; ++sl) {
-        if (sl >= sa && sl <= sb) {
-            if (sl + R - 1 <= sb) issue_row(sl + R - 1);        // refills the slot consumed in the previous iteration
-            wait_vmcnt_le(min(R - 1, sb - sl) * nld_live);      // this row has landed (later rows may still be in flight)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            float* slot = ring + ((sl - sa) % R) * ROWF;
-            if (!pad_zero && any_outside) {
-                // replicate padding: out-of-image float4s take the nearest image pixel of this row (already in LDS)
+    // ---- main loop: one GROUP = F HR rows (local shifted rows F gl .. F gl + F - 1) opens local output row gl and retires row
+    //      gl - (TYB - 1).  The F phases are unrolled, so the tap row al = F m + q of open row m is a literal: no `al < TY` tests, and
+    //      which open rows exist (0 <= gl - m < nrows) is one bit mask per group instead of three compares per (row, m).  Round 4
+    //      (tools/ubench/smem_prefetch.hip, part C): the memory side of this kernel alone runs 36.6 us at 48 planes / 115 us at the
+    //      north-star unit -- the fold's ~25 scalar instructions and one exposed scalar-cache round trip per (row, m) were what the
+    //      kernel waited for.  The tap row of open row m + 1 is requested behind the first FMA of open row m (every lgkmcnt wait is
+    //      a wait for zero: scalar loads return out of order), the first one of an HR row in front of that row's DMA wait.
+    //      Same sums in the same order as before (and as degrade_generic_kernel): bit-identical.
+    const float* __restrict__ tbase = up ? taps + (size_t)p.n_tap_rows * (TY * TXP) : taps;   // mirrored walk: the row-reversed copy
+    struct TapRow { float k[TX]; };
+    auto load_taps = [&](int al) {                              // al literal after unrolling; the whole padded row exists for every al < TY
+        TapRow t;
+        const float* __restrict__ tp = tbase + al * TXP;
 #pragma unroll
-                for (int t = 0; t < NLD; ++t) {
-                    if (outside[t]) {
-                        const int c0 = col0 + 4 * (lane + kWave * t);
-                        const float e = slot[(c0 < 0 ? 0 : W - 1) - col0];
-                        *reinterpret_cast<f32x4*>(slot + 4 * (lane + kWave * t)) = f32x4{e, e, e, e};
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (int b = 0; b < TX; ++b) t.k[b] = tp[b];
+        return t;
+    };
+    const int n_groups = nrows + TYB - 1;
+    int rd_off = 0;                                             // ring slot (float offset) of the next row to consume: ((sl - sa) % R) * ROWF
+    for (int gl = 0; gl < n_groups; ++gl) {
+        unsigned vmask = 0;                                     // bit m: open row m (local output row gl - m) exists
+#pragma unroll
+        for (int m = 0; m < TYB; ++m) vmask |= (gl - m >= 0 && gl - m < nrows) ? (1u << m) : 0u;
+#pragma unroll
+        for (int q = 0; q < F; ++q) {
+            const int sl = F * gl + q;
+            if (sl >= sa && sl <= sb) {
+                TapRow tk = load_taps(q);                       // open row 0 (al = q < F <= TY): in flight across the DMA wait
+                if (sl + R - 1 <= sb) issue_row(sl + R - 1, rd_off == 0 ? (R - 1) * ROWF : rd_off - ROWF);   // refills the slot consumed in the previous iteration
+                // this row has landed (later rows may still be in flight); steady state = a literal count, no switch
+                if (sb - sl >= R - 1 && nld_live == NLD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * NLD) : "memory");
+                else wait_vmcnt_le(min(R - 1, sb - sl) * nld_live);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-            }
-            // ---- each lane reads the windows of its NX outputs (neighbour lanes overlap: that is the halo share)
-            float win[NX][NWG * G];
+                float* slot = ring + rd_off;
+                rd_off = rd_off == (R - 1) * ROWF ? 0 : rd_off + ROWF;
+                if (!pad_zero && any_outside) {
+                    // replicate padding: out-of-image float4s take the nearest image pixel of this row (already in LDS)
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));                // lane-derived offsets live only here (not across the whole loop)
 #pragma unroll
-            for (int x = 0; x < NX; ++x) {
-                const int base = F * (lane + kWave * x) + (HL - PW - OFF);
-#pragma unroll
-                for (int t = 0; t < NWG; ++t) {
-                    using V = typename VecT<G>::type;
-                    const V v = *reinterpret_cast<const V*>(slot + base + G * t);
-                    if constexpr (G == 4) {
-                        win[x][4 * t + 0] = v.x; win[x][4 * t + 1] = v.y; win[x][4 * t + 2] = v.z; win[x][4 * t + 3] = v.w;
-                    } else if constexpr (G == 2) {
-                        win[x][2 * t + 0] = v.x; win[x][2 * t + 1] = v.y;
-                    } else {
-                        win[x][t] = v;
+                    for (int t = 0; t < NLD; ++t) {
+                        if (outside[t]) {
+                            const int c0 = col0 + 4 * (ln + kWave * t);
+                            const float e = slot[(c0 < 0 ? 0 : W - 1) - col0];
+                            *reinterpret_cast<f32x4*>(slot + 4 * (ln + kWave * t)) = f32x4{e, e, e, e};
+                        }
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
-            }
-            // ---- fold the row into every open output row (local tap row F*m + q of slot m)
+                // ---- each lane reads the windows of its NX outputs (neighbour lanes overlap: that is the halo share)
+                float win[NX][NWG * G];
 #pragma unroll
-            for (int m = 0; m < TYB; ++m) {
-                const int al = F * m + q;
-                const int il = gl - m;
-                if (al < TY && il >= 0 && il < nrows) {  // wave-uniform
-                    const float* __restrict__ tp = taps + (up ? TY - 1 - al : al) * TXP;
-                    static_assert(OFF % 2 == 0, "window pairs (OFF + b, OFF + b + 1), b even, must be the aligned halves of the LDS reads");
+                for (int x = 0; x < NX; ++x) {
+                    const int base = F * (lane + kWave * x) + (HL - PW - OFF);
 #pragma unroll
-                    for (int b = 0; b < TX; b += 2) {
-                        if (b + 1 < TX) {
-                            const f32x2 kv = f32x2{tp[b], tp[b + 1]};
-#pragma unroll
-                            for (int x = 0; x < NX; ++x)
-                                acc[m][x] = __builtin_elementwise_fma(kv, f32x2{win[x][OFF + b], win[x][OFF + b + 1]}, acc[m][x]);
-                        } else {        // odd TX: the last tap (even index) joins the even partial sum; never multiply a padded zero tap
-                            const float kv = tp[b];     // with a pixel outside the window (0 x NaN)
-#pragma unroll
-                            for (int x = 0; x < NX; ++x) acc[m][x].x = fmaf(kv, win[x][OFF + b], acc[m][x].x);
+                    for (int t = 0; t < NWG; ++t) {
+                        using V = typename VecT<G>::type;
+                        const V v = *reinterpret_cast<const V*>(slot + base + G * t);
+                        if constexpr (G == 4) {
+                            win[x][4 * t + 0] = v.x; win[x][4 * t + 1] = v.y; win[x][4 * t + 2] = v.z; win[x][4 * t + 3] = v.w;
+                        } else if constexpr (G == 2) {
+                            win[x][2 * t + 0] = v.x; win[x][2 * t + 1] = v.y;
+                        } else {
+                            win[x][t] = v;
                         }
                     }
                 }
+                // ---- fold the row into every open output row (local tap row F*m + q of slot m)
+                static_assert(OFF % 2 == 0, "window pairs (OFF + b, OFF + b + 1), b even, must be the aligned halves of the LDS reads");
+#pragma unroll
+                for (int m = 0; m < TYB; ++m) {
+                    if (F * m + q < TY) {                       // literal
+                        const bool more = F * (m + 1) + q < TY; // literal: open row m + 1 has a tap row in this phase
+                        TapRow tn = tk;
+                        auto fold_pair = [&](int b) {
+                            if (b + 1 < TX) {
+                                const f32x2 kv = f32x2{tk.k[b], tk.k[b + 1]};
+#pragma unroll
+                                for (int x = 0; x < NX; ++x)
+                                    acc[m][x] = __builtin_elementwise_fma(kv, f32x2{win[x][OFF + b], win[x][OFF + b + 1]}, acc[m][x]);
+                            } else {        // odd TX: the last tap (even index) joins the even partial sum; never multiply a padded zero tap
+                                const float kv = tk.k[b];       // with a pixel outside the window (0 x NaN)
+#pragma unroll
+                                for (int x = 0; x < NX; ++x) acc[m][x].x = fmaf(kv, win[x][OFF + b], acc[m][x].x);
+                            }
+                        };
+                        if ((vmask >> m) & 1u) {               // wave-uniform
+                            asm volatile("");                   // keep it a branch (if-converted, every accumulator gets a select per row)
+                            fold_pair(0);                       // first use of tk: the wait for it (and for the window reads) sits here
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more) tn = load_taps(F * (m + 1) + q);   // next open row's taps: requested under this row's FMAs
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int b = 2; b < TX; b += 2) fold_pair(b);
+                        } else if (more) {
+                            tn = load_taps(F * (m + 1) + q);
+                        }
+                        tk = tn;
+                    }
+                }
+                // the LDS reads above must retire before a later iteration's DMA overwrites this slot
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            // the LDS reads above must retire before a later iteration's DMA overwrites this slot
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
-        if (++q == F) {
+        {
             // ---- group finished: slot TYB-1 holds local output row il = gl-(TYB-1), complete
             const int il = gl - (TYB - 1);
             if (il >= 0 && il < nrows) {
                 const int i = up ? i1 - 1 - il : i0 + il;
                 if (p.noise_mode == KMSR_NOISE_GAUSSIAN && (il == 0 || (i & 3) == (up ? 3 : 0))) {
-#pragma unroll
+                    unsigned long long sd = p.seed;
+                    asm volatile("" : "+s"(sd));   // (same for the seed: its 20 Philox round keys were hoisted and spilled to VGPR lanes)
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));   // derived from the lane id HERE: hoisted out of the group loop, the Philox key products and
+#pragma unroll                                     // Box-Muller constants took 25 VGPRs for the whole kernel (103 -> 4 instead of 6 waves per SIMD)
                     for (int x = 0; x < NX; ++x)
-                        eps4(p.seed, p.offset, nz_plane, (unsigned)(i >> 2), (unsigned)(xs0 + lane + kWave * x), z[x]);
+                        eps4(sd, p.offset, nz_plane, (unsigned)(i >> 2), (unsigned)(xs0 + ln + kWave * x), z[x]);
                 }
+                // wave-uniform row bases + a 32-bit lane index: scalar-base addressing, no 64-bit per-lane column kept across the loop
+                float* __restrict__ orow = lr + ((long long)plane * p.h + i) * p.w + xs0;
+                const float* __restrict__ nrow = p.noise_mode == KMSR_NOISE_POOL ? npl + (long long)i * p.w + xs0 : nullptr;
 #pragma unroll
                 for (int x = 0; x < NX; ++x) {
-                    const int xo = xs0 + lane + kWave * x;
-                    if (xo < p.w) {
+                    const unsigned xl = (unsigned)(lane + kWave * x);
+                    if (xs0 + (int)xl < p.w) {
                         float v = acc[TYB - 1][x].x + acc[TYB - 1][x].y;
                         if (p.noise_mode == KMSR_NOISE_GAUSSIAN) v += sig * pick4(z[x], i & 3);
-                        else if (p.noise_mode == KMSR_NOISE_POOL) v += npl[(long long)i * p.w + xo];
-                        lr[((long long)plane * p.h + i) * p.w + xo] = v;
+                        else if (p.noise_mode == KMSR_NOISE_POOL) v += nrow[xl];
+                        orow[xl] = v;
                     }
                 }
             }
@@ -411,8 +463,6 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
                 for (int x = 0; x < NX; ++x) acc[m][x] = acc[m - 1][x];
 #pragma unroll
             for (int x = 0; x < NX; ++x) acc[0][x] = f32x2{0.f, 0.f};
-            q = 0;
-            ++gl;
         }
     }
 }
@@ -522,7 +572,7 @@ extern "C" int kmsr_degrade_out_shape(const kmsr_degrade_desc* d, int32_t* h, in
 extern "C" size_t kmsr_degrade_workspace_bytes(const kmsr_degrade_desc* d) {
     Geometry g;
     if (geometry(d, &g)) return 0;
-    return (size_t)g.rows * g.TY * g.TXP * sizeof(float);
+    return 2 * (size_t)g.rows * g.TY * g.TXP * sizeof(float);    // tap table + its row-reversed copy
 }
 
 extern "C" int kmsr_degrade_uses_fast_path(const kmsr_degrade_desc* d, const void* hr) {
@@ -551,7 +601,7 @@ extern "C" int kmsr_degrade_f32(const kmsr_degrade_desc* d, const float* hr, con
         if (!noise_idx && d->pool_size < d->N) return fail(KMSR_E_SHAPE, "pool_size=%d < N=%d with identity index", d->pool_size, d->N);
     }
     if (d->hr_stride_h < d->W) return fail(KMSR_E_BADARG, "hr_stride_h < W");
-    const size_t need = (size_t)g.rows * g.TY * g.TXP * sizeof(float);
+    const size_t need = 2 * (size_t)g.rows * g.TY * g.TXP * sizeof(float);
     if (!workspace || workspace_bytes < need)
         return fail(KMSR_E_NOMEM, "workspace %zu B < required %zu B", workspace_bytes, need);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -567,6 +617,7 @@ extern "C" int kmsr_degrade_f32(const kmsr_degrade_desc* d, const float* hr, con
     p.N = d->N; p.C = d->C; p.H = d->H; p.W = d->W; p.h = g.h; p.w = g.w;
     p.F = g.F; p.TY = g.TY; p.TX = g.TX; p.TXP = g.TXP; p.ph = g.ph; p.pw = g.pw;
     p.taps = static_cast<const float*>(workspace);
+    p.n_tap_rows = g.rows;
     p.n_kernels = d->n_kernels; p.kidx = kernel_idx; p.sigma = sigma; p.noise = noise;
     p.nidx = reinterpret_cast<const long long*>(noise_idx); p.lr = lr;
     p.seed = d->seed; p.offset = d->offset;
