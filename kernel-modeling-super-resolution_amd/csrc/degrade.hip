@@ -181,27 +181,12 @@ template <> struct VecT<1> { using type = float; };
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-// s_waitcnt needs an immediate; n is wave-uniform.  Anything above the table waits for more than asked (safe).
-__device__ __forceinline__ void wait_vmcnt_le(int n) {
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    }
+// 16 bytes per lane from (base + soff + voff) into LDS at lds_dst + 16 lane; voff >= records: the hardware writes zeros.  A plain
+// function on purpose: with the builtin call inside the kernel template, hipcc's HOST pass silently dropped every instantiation and
+// the library ended up without the kernel's launch stubs (undefined symbol at load time; no diagnostic).
+__device__ __forceinline__ void dma16(const float* base, unsigned records, float* lds_dst, unsigned voff, unsigned soff) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, records, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_dst, 16, voff, soff, 0, KMSR_DMA_AUX);
 }
 
 // Row-streaming kernel.  R = LDS ring slots per wave: R-1 HR rows are in flight (LDS-DMA, no staging VGPRs)
@@ -243,29 +228,30 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
     float* ring = &lds[wid][0][0];
     const bool pad_zero = p.pad_zero != 0;
 
-    // ---- per-lane staging map.  Float4 q of a row segment covers HR columns col0+4q .. +3; W % 4 == 0 and
-    //      col0 % 4 == 0, so it is either entirely inside the image (fetched by LDS-DMA) or entirely outside
-    //      (zero padding: zero-filled once; replicate padding: rewritten per row from the edge pixel).
-    bool inside[NLD], outside[NLD], live[NLD];
-    int nld_live = 0;
+    // ---- per-lane staging map.  Float4 q of a row segment covers HR columns col0+4q .. +3; W % 4 == 0 and col0 % 4 == 0, so it
+    //      is either entirely inside the image or entirely outside.  Rows are staged by BUFFER LDS-DMA on one descriptor per plane
+    //      (records = the plane's extent): the lane's column is the VGPR offset, the row position the scalar offset (which gfx950's
+    //      range check INCLUDES -- a one-row descriptor zeroes every row but the first).  Float4s outside the image carry an offset
+    //      of 2^31 (past any plane this path accepts, whatever the row), for which the hardware writes zeros
+    //      -- zero padding costs nothing, every row is exactly NLD instructions under the full exec mask (no per-instruction mask
+    //      juggling, no 64-bit per-lane addresses; tools/ubench/buffer_lds_oob.hip).  Replicate padding rewrites those float4s per
+    //      row from the edge pixel.  Only the last instruction's lanes past the segment end are masked off (they would write the
+    //      neighbouring slot).
+    constexpr unsigned kOOB = 0x80000000u;
+    unsigned voff[NLD];
+    bool outside[NLD];
     bool any_outside = false;
 #pragma unroll
     for (int t = 0; t < NLD; ++t) {
         const int q = lane + kWave * t;
         const int c0 = col0 + 4 * q;
-        inside[t] = q < NV && c0 >= 0 && c0 + 3 < W;
-        outside[t] = q < NV && !inside[t];
-        live[t] = __ballot(inside[t]) != 0ull;   // wave-uniform: is the t-th DMA instruction issued at all
-        nld_live += live[t] ? 1 : 0;
+        const bool in = c0 >= 0 && c0 + 3 < W;
+        voff[t] = in ? (unsigned)c0 * 4u : kOOB;
+        outside[t] = q < NV && !in;
         any_outside = any_outside || (__ballot(outside[t]) != 0ull);
     }
-    if (pad_zero && any_outside) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int t = 0; t < NLD; ++t)
-                if (outside[t]) *reinterpret_cast<f32x4*>(ring + r * ROWF + 4 * (lane + kWave * t)) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    const unsigned row_bytes = (unsigned)p.sH * 4u;              // host: (H - 1) * sH + W < 2^29 elements on this path (row offset + 2^31 does not wrap)
+    const unsigned plane_bytes = ((unsigned)(H - 1) * (unsigned)p.sH + (unsigned)W) * 4u;
 
     // accumulators as register PAIRS: .x collects the taps at even column index b, .y the odd ones (v_pk_fma_f32 does two taps per
     // instruction -- the fold loop is VALU-issue bound: 13 x NX x ~3.25 open rows scalar FMAs per HR row before); out = .x + .y.
@@ -306,15 +292,12 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
     auto issue_row = [&](int sl, int slot_off) {   // sl wave-uniform, sa <= sl <= sb; slot_off = ((sl - sa) % R) * ROWF (kept as a running offset)
         const int s = up ? s_top - sl : F * i0 + sl;
         const int r = min(max(s - PH, 0), H - 1);               // replicate padding clamps the row
-        const float* __restrict__ rp = img + (long long)r * p.sH + col0;
+        const unsigned soff = (unsigned)r * row_bytes;
         float* slot = ring + slot_off;
 #pragma unroll
         for (int t = 0; t < NLD; ++t) {
-            if (live[t]) {                                      // wave-uniform: exactly one VMEM instruction
-                if (inside[t])                                  // exec mask; LDS dest = slot + 256 t + 4 lane
-                    __builtin_amdgcn_global_load_lds((glb_void_t*)(rp + 4 * (lane + kWave * t)),
-                                                     (lds_void_t*)(slot + 4 * kWave * t), 16, 0, KMSR_DMA_AUX);
-            }
+            if (t < NLD - 1 || NV % kWave == 0 || lane < NV - kWave * (NLD - 1))   // literal except for the last, partial instruction
+                dma16(img, plane_bytes, slot + 4 * kWave * t, voff[t], soff);
         }
     };
 
@@ -352,8 +335,9 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
                 TapRow tk = load_taps(q);                       // open row 0 (al = q < F <= TY): in flight across the DMA wait
                 if (sl + R - 1 <= sb) issue_row(sl + R - 1, rd_off == 0 ? (R - 1) * ROWF : rd_off - ROWF);   // refills the slot consumed in the previous iteration
                 // this row has landed (later rows may still be in flight); steady state = a literal count, no switch
-                if (sb - sl >= R - 1 && nld_live == NLD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * NLD) : "memory");
-                else wait_vmcnt_le(min(R - 1, sb - sl) * nld_live);
+                if (sb - sl >= R - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * NLD) : "memory");
+                else if (R > 2 && sb - sl == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the chunk's last row (or a deeper ring's tail: stricter than needed)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 float* slot = ring + rd_off;
@@ -552,6 +536,7 @@ bool fast_eligible(const kmsr_degrade_desc* d, const Geometry& g, const void* hr
     if (d->W % 4 || d->hr_stride_h % 4 || d->hr_stride_c % 4 || d->hr_stride_n % 4) return false;
     if (reinterpret_cast<uintptr_t>(hr) % 16) return false;
     if (g.h < 1 || g.w < 16) return false;  // narrow LR rows would leave most lanes idle
+    if ((long long)(d->H - 1) * d->hr_stride_h + d->W >= (1ll << 29)) return false;   // the row position is a 32-bit byte offset of the plane's buffer descriptor
     return true;
 }
 
