@@ -185,8 +185,10 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // function on purpose: with the builtin call inside the kernel template, hipcc's HOST pass silently dropped every instantiation and
 // the library ended up without the kernel's launch stubs (undefined symbol at load time; no diagnostic).
 __device__ __forceinline__ void dma16(const float* base, unsigned records, float* lds_dst, unsigned voff, unsigned soff) {
+#ifndef KMSR_ABL_NO_DMA   // timing-only ablation builds (tools/diag): the compute side alone
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, records, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_dst, 16, voff, soff, 0, KMSR_DMA_AUX);
+#endif
 }
 
 // Row-streaming kernel.  R = LDS ring slots per wave: R-1 HR rows are in flight (LDS-DMA, no staging VGPRs)
@@ -383,6 +385,9 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
                         const bool more = F * (m + 1) + q < TY; // literal: open row m + 1 has a tap row in this phase
                         TapRow tn = tk;
                         auto fold_pair = [&](int b) {
+#ifdef KMSR_ABL_NO_FOLD   // timing-only ablation builds (tools/diag): the memory side + tap loads + window reads alone
+                            if (b > 0) return;
+#endif
                             if (b + 1 < TX) {
                                 const f32x2 kv = f32x2{tk.k[b], tk.k[b + 1]};
 #pragma unroll
