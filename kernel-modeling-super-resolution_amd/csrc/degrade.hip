@@ -201,7 +201,10 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
     using Cfg = RowCfg<F, TY, TX, PH, PW, NX>;
     constexpr int TYB = Cfg::TYB, G = Cfg::G, NWG = Cfg::NWG, OFF = Cfg::OFF, HL = Cfg::HL;
     constexpr int ROWF = Cfg::ROWF, NV = Cfg::NV, NLD = Cfg::NLD, SW = Cfg::SW, TXP = Cfg::TXP;
-    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][R][ROWF];   // the ONLY LDS object (guide 4a)
+#ifndef KMSR_ABL_LDS_PAD
+#define KMSR_ABL_LDS_PAD 0      // timing-only builds: floats of padding per ring slot = fewer resident workgroups per CU
+#endif
+    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][R][ROWF + KMSR_ABL_LDS_PAD];   // the ONLY LDS object (guide 4a)
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -423,7 +426,11 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock)
             const int il = gl - (TYB - 1);
             if (il >= 0 && il < nrows) {
                 const int i = up ? i1 - 1 - il : i0 + il;
+#ifdef KMSR_ABL_NO_NOISE   // timing-only ablation build: the Gaussian stream is never generated (z stays 0)
+                if (false) {
+#else
                 if (p.noise_mode == KMSR_NOISE_GAUSSIAN && (il == 0 || (i & 3) == (up ? 3 : 0))) {
+#endif
                     unsigned long long sd = p.seed;
                     asm volatile("" : "+s"(sd));   // (same for the seed: its 20 Philox round keys were hoisted and spilled to VGPR lanes)
                     int ln = lane;
@@ -648,8 +655,21 @@ extern "C" int kmsr_degrade_f32(const kmsr_degrade_desc* d, const float* hr, con
     p.n_units = (int)units;
     p.n_blocks = ceil_div(p.n_units, kWavesPerBlock);
     const dim3 grid(p.n_blocks), block(kWave * kWavesPerBlock);
-#define KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, NX_, R_) \
-    degrade_rowstream_kernel<F_, TY_, TX_, PH_, PW_, NX_, R_><<<grid, block, 0, stream>>>(hr, p.taps, sigma, noise, lr, p)
+    // Resident workgroups per CU.  A grid that does not fill every CU to its LDS limit is packed unevenly by the dispatcher (the
+    // north-star unit: 1280 workgroups on 256 CUs at 6 per CU = some CUs carry 24 waves and set the kernel's time, others idle).
+    // Unreferenced dynamic LDS caps the residency at ceil(workgroups / CUs), which spreads them evenly: 151 -> 141 us on that unit
+    // (profiles/r04_degrade_occupancy.log).
+    auto spread_lds = [&](size_t static_bytes) -> size_t {
+        const int n_cu = 256, lds_cu = 160 * 1024;
+        const int target = ceil_div(p.n_blocks, n_cu);
+        if (static_bytes == 0 || target >= (int)(lds_cu / static_bytes)) return 0;
+        const size_t per = std::min<size_t>((size_t)(lds_cu / target) / 1024 * 1024 - 1024, 64 * 1024);   // 1 KB of slack: an exact fit (5 x 32 KB) left only 4 resident
+        return per > static_bytes ? per - static_bytes : 0;
+    };
+#define KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, NX_, R_)                                                                        \
+    degrade_rowstream_kernel<F_, TY_, TX_, PH_, PW_, NX_, R_>                                                                \
+        <<<grid, block, spread_lds(sizeof(float) * kWavesPerBlock * R_ * RowCfg<F_, TY_, TX_, PH_, PW_, NX_>::ROWF), stream>>>( \
+            hr, p.taps, sigma, noise, lr, p)
 #define X(F_, TY_, TX_, PH_, PW_)                                                      \
     if (g.F == F_ && g.TY == TY_ && g.TX == TX_ && g.ph == PH_ && g.pw == PW_) {       \
         if (NX == 2) KMSR_LAUNCH(F_, TY_, TX_, PH_, PW_, 2, kRing);                    \

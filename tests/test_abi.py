@@ -117,8 +117,9 @@ def test_error_codes_and_messages_without_gpu():
     # null tensors are rejected before any launch
     d = _desc()
     assert lib.kmsr_degrade_f32(d, None, None, None, None, None, None, None, None, 0, None) == L.KMSR_E_BADARG
-    assert lib.kmsr_degrade_workspace_bytes(_desc(factor=4)) == 5 * 16 * 16 * 4
-    assert lib.kmsr_degrade_workspace_bytes(_desc(factor=4, down_mode=L.DOWN_STRIDE)) == 5 * 13 * 16 * 4
+    # the effective tap table [rows][TY][TXP] fp32 and its row-reversed copy (read by the bottom-up chunks of the row-streaming kernel)
+    assert lib.kmsr_degrade_workspace_bytes(_desc(factor=4)) == 2 * 5 * 16 * 16 * 4
+    assert lib.kmsr_degrade_workspace_bytes(_desc(factor=4, down_mode=L.DOWN_STRIDE)) == 2 * 5 * 13 * 16 * 4
 
 
 def test_upsampler_frame_argument_checks_without_gpu():
