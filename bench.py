@@ -298,13 +298,33 @@ class DegradeSRWorkload:
         ms = sorted(a.elapsed_time(b) for a, b in self._ev_deg)
         if not ms:
             return None
-        kernel_ms = ms[len(ms) // 2]
+        in_step_ms = ms[len(ms) // 2]
+        # An event pair around ONE ~50 us launch also brackets the launch gap on both sides (8-10 us here: 58.9 us by that bracket against
+        # 47-50 us per launch in the rocprofv3 trace of the same command).  The kernel's duration is therefore taken from the same call
+        # issued back to back on the launch stream (same tensors, tap table built), like the north-star unit below; the in-step bracket
+        # is reported beside it.
+        launches = 20
+        def one():
+            kmsr_amd.degrade_batch(self.hr, self.bank, 4, down="stride", pad="zero", normalize=False, kernel_idx=self.kid, sigma=self.sigma,
+                                   noise="gaussian", seed=42, offset=self.step_no, sample_base=self.sample_base, out=self.lr, workspace=self.ws,
+                                   taps_ready=True, flags=L.FLAG_FORCE_FAST)
+        for _ in range(3):
+            one()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            one()
+        e1.record()
+        torch.cuda.synchronize()
+        kernel_ms = e0.elapsed_time(e1) / launches
         ach = self.deg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         out = {"bound": "hbm", "kernel": "degrade_rowstream_kernel (V-B: 13x13 stride 4, zero pad, Philox noise) on HR [16,3,1024,1024]",
                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                "traffic": None, "algorithmic_bytes_per_launch": self.deg_bytes_per_launch,
-               "kernel_ms": round(kernel_ms, 4), "launches_timed": len(ms),
-               "what": "HIP events around the kmsr_degrade_f32 call of every instrumented step (tap table already built)"}
+               "kernel_ms": round(kernel_ms, 4), "launches_timed": launches,
+               "kernel_ms_in_step_bracket": round(in_step_ms, 4), "in_step_launches_timed": len(ms),
+               "what": f"{launches} back-to-back kmsr_degrade_f32 launches of the step's own call (tap table built), HIP events on the launch stream; "
+                       "kernel_ms_in_step_bracket = one event pair around the single launch inside every instrumented step (includes the launch gap)"}
         out.update(static_traffic_degrade("config2_hr16x3x1024x1024"))
         return out
 
@@ -315,14 +335,20 @@ class DegradeSRWorkload:
         wl = DegradeWorkload(self.hr.device, 0)
         for _ in range(3):
             wl.step()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(launches):
-            wl.step()
-        e1.record()
-        torch.cuda.synchronize()
-        out = wl.roofline(e0.elapsed_time(e1) / launches)
-        out["what"] = f"{launches} back-to-back launches on HR [32,5,1024,1024] (tap table built once), HIP events on the launch stream"
+        rounds = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(launches):
+                wl.step()
+            e1.record()
+            torch.cuda.synchronize()
+            rounds.append(e0.elapsed_time(e1) / launches)
+        out = wl.roofline(sorted(rounds)[len(rounds) // 2])
+        out["kernel_ms_rounds"] = [round(r, 4) for r in rounds]
+        out["what"] = (f"median of {len(rounds)} rounds of {launches} back-to-back launches on HR [32,5,1024,1024] (tap table built once), HIP events on the "
+                       "launch stream.  This figure moves by +-8 % between processes on one box (136 / 150 / 163 us seen for two builds in one call, "
+                       "profiles/r04_bench_degrade_ab.log) while the rounds inside a process agree: compare builds in one process order, not across lines")
         del wl
         return out
 
