@@ -127,7 +127,7 @@ def train_moe(model, D, patches, real_ds, total_iters=5000, lr=1e-4, temp_range=
         hist[i, 0], hist[i, 1], hist[i, 2] = loss_D.detach(), loss_G_adv.detach(), reg_loss.detach()
         if log is not None and log_every and i % log_every == 0:
             counts = torch.bincount(weights.argmax(dim=1), minlength=model.n_kernels)     # :226-229
-            log(f"Iter {i} | Temp: {temp:.2f} | D: {float(loss_D):.3f} | Selection Dist: {counts.cpu().numpy()}")
+            log(f"Iter {i} | Temp: {temp:.2f} | D: {float(loss_D.detach()):.3f} | Selection Dist: {counts.cpu().numpy()}")
     return hist.cpu().numpy()
 
 
