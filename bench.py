@@ -666,6 +666,14 @@ class StubWorkload:
         return None
 
 
+def stub_secondary_legs(mode, rank):
+    """Stand-in for the secondary legs on the CPU stub workload (tests only): KMSR_BENCH_STUB_SECONDARY=ok returns at once,
+    =hang never returns (a collective that stalls on every rank), =hang1 stalls on rank 1 only while rank 0 finishes."""
+    if mode == "hang" or (mode == "hang1" and rank == 1):
+        time.sleep(3600)
+    return {"stub": True}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with N > 1 and no process group in the environment: this parent -- which has made NO GPU call
     (importing torch / kmsr_amd does not initialise HIP) -- starts N fresh rank processes with the same launcher the driver uses
@@ -816,18 +824,11 @@ def main():
                     "up1/PS/up2/PS/tail run as ONE conv5x5 64->48 + PixelShuffle(4) launch + one border-class frame launch",
             "issued_mfma_flops_per_step": f2, "issued_mfma_tflops": round(f2 * args.steps * world / el2 / 1e12, 2)}}
 
-    secondary = None
-    if args.workload == "degrade_sr" and not args.no_secondary:
-        hold = wl.roofline_degrade_northstar() if rank == 0 else None        # before the big secondary workloads exist
-        try:
-            secondary = secondary_lines(device, rank, world, kd, sync)
-        except Exception as e:          # the headline above is already measured: report it, and say loudly what broke behind it
-            import traceback
-            secondary = {"failed": True, "error": f"{type(e).__name__}: {e}", "where": traceback.format_exc().strip().splitlines()[-3:]}
-            print(f"[bench] rank {rank}: secondary legs failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
-    else:
-        hold = None
-
+    # Everything of the line that needs the GPU is computed BEFORE the secondary legs, so that the headline can still be reported
+    # if a leg behind it stalls (see the watchdog below).
+    stub_secondary = args.workload == "stub" and os.environ.get("KMSR_BENCH_STUB_SECONDARY")      # tests/test_bench_launch.py
+    run_secondary = (args.workload == "degrade_sr" and not args.no_secondary) or bool(stub_secondary)
+    out = None
     if rank == 0:
         total_patches = wl.patches_per_step * args.steps * world
         out = {
@@ -852,7 +853,7 @@ def main():
         }
         if hasattr(wl, "roofline_degrade"):
             out["roofline_degrade"] = wl.roofline_degrade()
-            out["roofline_degrade_northstar"] = hold if hold is not None else wl.roofline_degrade_northstar()
+            out["roofline_degrade_northstar"] = wl.roofline_degrade_northstar()      # before the big secondary workloads exist
         if instrumented is not None:
             out["instrumented_ms_per_step"] = instrumented
         if args.workload == "degrade_sr":
@@ -860,10 +861,44 @@ def main():
             out["step_mfma"] = {"issued_flops_per_step": f, "issued_tflops": round(f * args.steps * world / elapsed / 1e12, 2),
                                 "frac_of_peak": round(f * args.steps / elapsed / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                                 "algorithmic_flops_per_step": wl.flops_per_patch * wl.B}
-        if args.workload == "degrade_sr":
             out["config"]["upsampler"] = "collapsed conv5x5+PS4 (exact linear rewrite of up1/PS/up2/PS/tail)" if fuse else "layer-by-layer"
         if variants:
             out["variants"] = variants
+
+    secondary = None
+    if run_secondary:
+        # Watchdog (N > 1 only): config 3's leg is the one place where this file runs a data-path collective (the flat-bucket
+        # gradient all-reduce).  Should it stall -- a rank that died, a collective that never completes -- no rank would ever
+        # reach the print below and the measured headline would be lost with it.  Every rank arms the same deadline; when it
+        # passes, rank 0 prints the line it already holds (secondary marked failed) and every rank leaves with os._exit, which
+        # needs neither the GPU nor the process group.
+        watchdog = None
+        if world > 1:
+            import threading
+            limit = float(os.environ.get("KMSR_BENCH_SECONDARY_TIMEOUT", "300"))
+
+            def give_up():
+                if rank == 0:
+                    out["secondary"] = {"failed": True, "error": f"secondary legs did not finish within {limit:.0f} s on {world} ranks "
+                                        "(watchdog; the headline above was measured before them)"}
+                    print(json.dumps(out), flush=True)
+                print(f"[bench] rank {rank}: secondary legs exceeded {limit:.0f} s, leaving", file=sys.stderr, flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(limit, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            secondary = stub_secondary_legs(stub_secondary, rank) if stub_secondary else secondary_lines(device, rank, world, kd, sync)
+        except Exception as e:          # the headline above is already measured: report it, and say loudly what broke behind it
+            import traceback
+            secondary = {"failed": True, "error": f"{type(e).__name__}: {e}", "where": traceback.format_exc().strip().splitlines()[-3:]}
+            print(f"[bench] rank {rank}: secondary legs failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        if watchdog is not None:
+            # a rank whose legs FAILED stays under the watchdog while it waits for the others: they may be inside a collective it left
+            if not (isinstance(secondary, dict) and secondary.get("failed")):
+                watchdog.cancel()
+
+    if rank == 0:
         if secondary:
             out["secondary"] = secondary
         if not args.no_cpu_baseline and world == 1 and hasattr(wl, "cpu_baseline"):

@@ -20,6 +20,7 @@ def init_from_env(backend=None, force=False):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (read when the HSA runtime starts): RCCL needs it on this pool
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -50,3 +50,20 @@ def test_bench_refuses_gpus_world_size_mismatch():
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stub", "--no-cpu-baseline", "--gpus", "2",
                            "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=e, timeout=120)
     assert proc.returncode != 0 and "WORLD_SIZE=1" in proc.stderr and not proc.stdout.strip()
+
+
+def test_bench_secondary_watchdog_still_reports_the_headline():
+    """A secondary leg that never returns on N > 1 ranks (a stalled collective) must not cost the measured headline: every rank
+    arms the same deadline, rank 0 prints the line it already holds with secondary marked failed, all ranks exit 0."""
+    ok = _line(_run(["--gpus", "2", "--steps", "3", "--warmup", "1"], KMSR_BENCH_STUB_SECONDARY="ok"))
+    assert ok["secondary"] == {"stub": True} and ok["n_gpus"] == 2
+    for mode in ("hang", "hang1"):
+        r = _line(_run(["--gpus", "2", "--steps", "3", "--warmup", "1"], KMSR_BENCH_STUB_SECONDARY=mode, KMSR_BENCH_SECONDARY_TIMEOUT="3"))
+        assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["value"] > 0
+        if mode == "hang":
+            assert r["secondary"]["failed"] and "watchdog" in r["secondary"]["error"]
+        else:                      # rank 0's own legs finished; rank 1 left through its watchdog
+            assert r["secondary"] == {"stub": True}
+    # a single rank arms no watchdog (nothing to wait for)
+    one = _line(_run(["--gpus", "1", "--steps", "3", "--warmup", "1"], KMSR_BENCH_STUB_SECONDARY="ok"))
+    assert one["secondary"] == {"stub": True}
