@@ -865,6 +865,8 @@ def main():
         if variants:
             out["variants"] = variants
 
+    import threading
+    emit_lock, emitted = threading.Lock(), []
     secondary = None
     if run_secondary:
         # Watchdog (N > 1 only): config 3's leg is the one place where this file runs a data-path collective (the flat-bucket
@@ -874,14 +876,16 @@ def main():
         # needs neither the GPU nor the process group.
         watchdog = None
         if world > 1:
-            import threading
             limit = float(os.environ.get("KMSR_BENCH_SECONDARY_TIMEOUT", "300"))
 
             def give_up():
                 if rank == 0:
-                    out["secondary"] = {"failed": True, "error": f"secondary legs did not finish within {limit:.0f} s on {world} ranks "
-                                        "(watchdog; the headline above was measured before them)"}
-                    print(json.dumps(out), flush=True)
+                    with emit_lock:                    # never a second line: the main thread may be printing right now
+                        if not emitted:
+                            emitted.append(True)
+                            out["secondary"] = {"failed": True, "error": f"secondary legs did not finish within {limit:.0f} s on {world} "
+                                                "ranks (watchdog; the headline above was measured before them)"}
+                            print(json.dumps(out), flush=True)
                 print(f"[bench] rank {rank}: secondary legs exceeded {limit:.0f} s, leaving", file=sys.stderr, flush=True)
                 os._exit(0)
             watchdog = threading.Timer(limit, give_up)
@@ -899,11 +903,15 @@ def main():
                 watchdog.cancel()
 
     if rank == 0:
-        if secondary:
-            out["secondary"] = secondary
-        if not args.no_cpu_baseline and world == 1 and hasattr(wl, "cpu_baseline"):
-            out["cpu_baseline"] = wl.cpu_baseline()
-        print(json.dumps(out), flush=True)
+        cpu = wl.cpu_baseline() if not args.no_cpu_baseline and world == 1 and hasattr(wl, "cpu_baseline") else None
+        with emit_lock:
+            if not emitted:
+                emitted.append(True)
+                if secondary:
+                    out["secondary"] = secondary
+                if cpu is not None:
+                    out["cpu_baseline"] = cpu
+                print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
